@@ -1,0 +1,250 @@
+/* rusty_compression_amd.h -- C ABI of the MI355X-native randomized low-rank
+ * compression engine (librusty_compression_amd.so).
+ *
+ * This is the drop-in boundary for the hot path of rusty-compression v0.1.1
+ * (reference at /root/reference).  The reference has no FFI of its own: its
+ * arithmetic crosses into Fortran LAPACK inside src/pivoted_qr.rs:138-173 and
+ * through ndarray-linalg.  A maintainer swapping the hot path to the GPU binds
+ * ONE level higher, at the crate's own trait methods, so every entry point
+ * below names the reference interface it replaces (file:line).  The reference
+ * side binding (Rust `extern "C"` block + trait impls) is in INTEGRATION.md
+ * and bindings/rust/.
+ *
+ * Conventions
+ *  - All matrix arguments are DEVICE memory described by `rc_matrix` (an
+ *    ndarray-style strided view: element (i, j) lives at
+ *    data[i*row_stride + j*col_stride], strides in elements).  Any layout is
+ *    accepted (C order, Fortran order, transposed views); inputs are never
+ *    modified (reference: every trait method borrows views and returns owned
+ *    arrays).  Outputs are caller-allocated.
+ *  - `_f64` / `_f32` select the scalar type (reference macros instantiate
+ *    f32/f64/c32/c64; complex is out of scope).
+ *  - Index vectors are int64, 0-based, in device memory (reference: usize,
+ *    src/qr.rs:36-39).
+ *  - Calls are asynchronous on the context's HIP stream unless they return a
+ *    host scalar (documented per function); rc_synchronize() waits.
+ *  - Every function returns rc_status; rc_last_error_message() explains it.
+ *    Status values mirror RustyCompressionError (src/types.rs:11-21).
+ *  - One context per host thread per GPU; contexts share nothing.
+ */
+#ifndef RUSTY_COMPRESSION_AMD_H
+#define RUSTY_COMPRESSION_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RC_ABI_VERSION 1
+
+typedef int32_t rc_status;
+enum {
+    RC_OK = 0,
+    RC_LINALG_ERROR = 1,      /* RustyCompressionError::LinalgError      src/types.rs:13-14 */
+    RC_COMPRESSION_ERROR = 2, /* RustyCompressionError::CompressionError src/types.rs:15-16 */
+    RC_LAYOUT_ERROR = 3,      /* RustyCompressionError::LayoutError      src/types.rs:17-18 */
+    RC_PIVOTED_QR_ERROR = 4,  /* RustyCompressionError::PivotedQRError   src/types.rs:19-20 */
+    RC_INVALID_ARGUMENT = 5,  /* the reference panics (assert!) on these: src/qr.rs:99, src/permutation.rs:96-99 */
+    RC_RUNTIME_ERROR = 6      /* HIP runtime failure (no reference counterpart) */
+};
+
+/* ndarray-style strided device view; strides in ELEMENTS. */
+typedef struct rc_matrix {
+    void *data;
+    int64_t rows;
+    int64_t cols;
+    int64_t row_stride;
+    int64_t col_stride;
+} rc_matrix;
+
+typedef struct rc_context rc_context;
+
+/* CompressionType (src/lib.rs:82-87) */
+enum { RC_COMPRESS_ADAPTIVE = 0, RC_COMPRESS_RANK = 1 };
+/* MatrixPermutationMode (src/permutation.rs:7-16) */
+enum { RC_PERM_COL = 0, RC_PERM_ROW = 1, RC_PERM_COLINV = 2, RC_PERM_ROWINV = 3 };
+/* VectorPermutationMode (src/permutation.rs:19-24) */
+enum { RC_VPERM_INV = 0, RC_VPERM_NOINV = 1 };
+
+/* ---------------------------------------------------------------- context -- */
+int32_t rc_abi_version(void);
+/* stream: a hipStream_t (may be NULL = the device's default stream). */
+rc_status rc_create(rc_context **ctx, int32_t device, void *hip_stream);
+rc_status rc_destroy(rc_context *ctx);
+rc_status rc_set_stream(rc_context *ctx, void *hip_stream);
+rc_status rc_synchronize(rc_context *ctx);
+/* Pre-size the internal workspace arena (bytes); optional, it grows on demand. */
+rc_status rc_reserve_workspace(rc_context *ctx, size_t bytes);
+const char *rc_last_error_message(const rc_context *ctx);
+
+/* Plain device-memory helpers so a host without HIP bindings (the Rust crate)
+ * can stage ndarray data: upload -> call -> download. */
+rc_status rc_device_malloc(rc_context *ctx, size_t bytes, void **ptr);
+rc_status rc_device_free(rc_context *ctx, void *ptr);
+rc_status rc_memcpy_h2d(rc_context *ctx, void *dst_dev, const void *src_host, size_t bytes);
+rc_status rc_memcpy_d2h(rc_context *ctx, void *dst_host, const void *src_dev, size_t bytes); /* synchronous */
+
+/* ------------------------------------------------------- random_matrix.rs -- */
+/* RandomMatrix::random_gaussian (src/random_matrix.rs:21, :120-125): i.i.d.
+ * N(0,1), drawn in f64 and cast.  Element (i, j) is sample number i*cols + j
+ * (row-major draw order, as the reference fills) of the Philox4x32-10 stream
+ * (seed, offset); the reference's rand/rand_distr ziggurat stream cannot be
+ * reproduced sample-for-sample, so parity tests pass Omega explicitly. */
+rc_status rc_random_gaussian_f64(rc_context *ctx, rc_matrix out, uint64_t seed, uint64_t offset);
+rc_status rc_random_gaussian_f32(rc_context *ctx, rc_matrix out, uint64_t seed, uint64_t offset);
+
+/* --------------------------------------------------------------- types.rs -- */
+/* MatMat::matmat for dense matrices (src/types.rs:58-71, :103-121): Y = A X.
+ * One GEMM instead of the reference's per-column gemv loop (blanket impl,
+ * src/types.rs:145); results differ by summation order only. */
+rc_status rc_matmat_f64(rc_context *ctx, rc_matrix a, rc_matrix x, rc_matrix y);
+rc_status rc_matmat_f32(rc_context *ctx, rc_matrix a, rc_matrix x, rc_matrix y);
+/* ConjMatMat::conj_matmat (src/types.rs:88-101, :123-133): Y = A^H X (ncols(A) x ncols(X)). */
+rc_status rc_conj_matmat_f64(rc_context *ctx, rc_matrix a, rc_matrix x, rc_matrix y);
+rc_status rc_conj_matmat_f32(rc_context *ctx, rc_matrix a, rc_matrix x, rc_matrix y);
+/* ndarray `.dot` on two matrices (all call sites listed in SURVEY.md 2b N9):
+ * C = alpha * op(A) op(B) + beta * C, op = transpose when the flag is non-zero. */
+rc_status rc_gemm_f64(rc_context *ctx, int32_t trans_a, int32_t trans_b, double alpha, rc_matrix a, rc_matrix b, double beta, rc_matrix c);
+rc_status rc_gemm_f32(rc_context *ctx, int32_t trans_a, int32_t trans_b, float alpha, rc_matrix a, rc_matrix b, float beta, rc_matrix c);
+/* RelDiff (src/types.rs:162-196): host scalar out, synchronous. */
+rc_status rc_rel_diff_fro_f64(rc_context *ctx, rc_matrix first, rc_matrix second, double *out);
+rc_status rc_rel_diff_fro_f32(rc_context *ctx, rc_matrix first, rc_matrix second, float *out);
+
+/* --------------------------------------------------------- permutation.rs -- */
+/* invert_permutation_vector (src/permutation.rs:28-38) */
+rc_status rc_invert_permutation(rc_context *ctx, const int64_t *perm, int64_t n, int64_t *inverse);
+/* ApplyPermutationToMatrix::apply_permutation (src/permutation.rs:84-144).
+ * RC_INVALID_ARGUMENT when perm_len mismatches (the reference asserts). */
+rc_status rc_apply_permutation_matrix_f64(rc_context *ctx, int32_t mode, rc_matrix in, const int64_t *perm, int64_t perm_len, rc_matrix out);
+rc_status rc_apply_permutation_matrix_f32(rc_context *ctx, int32_t mode, rc_matrix in, const int64_t *perm, int64_t perm_len, rc_matrix out);
+/* ApplyPermutationToVector::apply_permutation (src/permutation.rs:153-183); vectors are n x 1 views. */
+rc_status rc_apply_permutation_vector_f64(rc_context *ctx, int32_t mode, rc_matrix in, const int64_t *perm, int64_t perm_len, rc_matrix out);
+rc_status rc_apply_permutation_vector_f32(rc_context *ctx, int32_t mode, rc_matrix in, const int64_t *perm, int64_t perm_len, rc_matrix out);
+
+/* ---------------------------------------------------------- pivoted_qr.rs -- */
+/* PivotedQR::pivoted_qr (src/pivoted_qr.rs:25-31, :81-183) = ?geqp3 + ?orgqr:
+ *   A P = Q R,  q: m x k,  r: k x n upper trapezoidal,  ind[j] = column of A at position j.
+ * k = q.cols = r.rows.  k == min(m, n) reproduces the reference exactly.
+ * k <  min(m, n) is the TRUNCATED factorization (stops after k Householder
+ * steps): q, r[:k] and ind[:k] equal the full factorization's, ind[k:] lists
+ * the remaining columns in the order the swaps left them. */
+rc_status rc_pivoted_qr_f64(rc_context *ctx, rc_matrix a, rc_matrix q, rc_matrix r, int64_t *ind);
+rc_status rc_pivoted_qr_f32(rc_context *ctx, rc_matrix a, rc_matrix q, rc_matrix r, int64_t *ind);
+/* PivotedQR::pivoted_lq (src/pivoted_qr.rs:32-41), LQ::compute_from (src/qr.rs:354-362):
+ *   P A = L Q,  l: m x k,  q: k x n,  ind: m. */
+rc_status rc_pivoted_lq_f64(rc_context *ctx, rc_matrix a, rc_matrix l, rc_matrix q, int64_t *ind);
+rc_status rc_pivoted_lq_f32(rc_context *ctx, rc_matrix a, rc_matrix l, rc_matrix q, int64_t *ind);
+
+/* ---------------------------------------------------------- compute_svd.rs -- */
+/* ComputeSVD::compute_svd (src/compute_svd.rs:18-27) = thin ?gesdd:
+ *   u: m x r, s: r (device, descending), vt: r x n, r = min(m, n).
+ * Singular vectors are unique up to a sign per pair; S and U diag(S) Vt match gesdd. */
+rc_status rc_compute_svd_f64(rc_context *ctx, rc_matrix a, rc_matrix u, double *s, rc_matrix vt);
+rc_status rc_compute_svd_f32(rc_context *ctx, rc_matrix a, rc_matrix u, float *s, rc_matrix vt);
+
+/* ------------------------------------------------------------------ qr.rs -- */
+/* compress_qr_tolerance / compress_lq_tolerance (src/qr.rs:187-200, :99-112):
+ * first i with |d_ii / d_00| < tol on the diagonal of `tri` (R or L).
+ * RC_COMPRESSION_ERROR if none, RC_INVALID_ARGUMENT unless 0 <= tol < 1. Synchronous. */
+rc_status rc_rank_by_tolerance_f64(rc_context *ctx, rc_matrix tri, double tol, int64_t *rank);
+rc_status rc_rank_by_tolerance_f32(rc_context *ctx, rc_matrix tri, double tol, int64_t *rank);
+/* QRTraits::to_mat (src/qr.rs:160-166): out = Q (R with COLINV permutation). */
+rc_status rc_qr_to_mat_f64(rc_context *ctx, rc_matrix q, rc_matrix r, const int64_t *ind, rc_matrix out);
+rc_status rc_qr_to_mat_f32(rc_context *ctx, rc_matrix q, rc_matrix r, const int64_t *ind, rc_matrix out);
+/* LQTraits::to_mat (src/qr.rs:73-77): out = (L with ROWINV permutation) Q. */
+rc_status rc_lq_to_mat_f64(rc_context *ctx, rc_matrix l, rc_matrix q, const int64_t *ind, rc_matrix out);
+rc_status rc_lq_to_mat_f32(rc_context *ctx, rc_matrix l, rc_matrix q, const int64_t *ind, rc_matrix out);
+/* QRTraits::column_id (src/qr.rs:270-309): c: m x k, z: k x n (both branches). */
+rc_status rc_qr_column_id_f64(rc_context *ctx, rc_matrix q, rc_matrix r, const int64_t *ind, rc_matrix c, rc_matrix z);
+rc_status rc_qr_column_id_f32(rc_context *ctx, rc_matrix q, rc_matrix r, const int64_t *ind, rc_matrix c, rc_matrix z);
+/* LQTraits::row_id (src/qr.rs:363-403): x: m x k, r_rows: k x n. */
+rc_status rc_lq_row_id_f64(rc_context *ctx, rc_matrix l, rc_matrix q, const int64_t *ind, rc_matrix x, rc_matrix r_rows);
+rc_status rc_lq_row_id_f32(rc_context *ctx, rc_matrix l, rc_matrix q, const int64_t *ind, rc_matrix x, rc_matrix r_rows);
+/* QRTraits::compute_from_range_estimate (src/qr.rs:311-323): range m x r', A m x n ->
+ * q: m x k, r: k x n, ind: n, with k = min(r', n). */
+rc_status rc_qr_from_range_estimate_f64(rc_context *ctx, rc_matrix range, rc_matrix a, rc_matrix q, rc_matrix r, int64_t *ind);
+rc_status rc_qr_from_range_estimate_f32(rc_context *ctx, rc_matrix range, rc_matrix a, rc_matrix q, rc_matrix r, int64_t *ind);
+
+/* ----------------------------------------------------------------- svd.rs -- */
+/* compress_svd_tolerance (src/svd.rs:87-101) on a device vector of singular values. Synchronous. */
+rc_status rc_svd_rank_by_tolerance_f64(rc_context *ctx, const double *s, int64_t len, double tol, int64_t *rank);
+rc_status rc_svd_rank_by_tolerance_f32(rc_context *ctx, const float *s, int64_t len, double tol, int64_t *rank);
+/* SVDTraits::to_mat (src/svd.rs:42-54): out = U diag(S) Vt. */
+rc_status rc_svd_to_mat_f64(rc_context *ctx, rc_matrix u, const double *s, rc_matrix vt, rc_matrix out);
+rc_status rc_svd_to_mat_f32(rc_context *ctx, rc_matrix u, const float *s, rc_matrix vt, rc_matrix out);
+/* SVDTraits::to_qr (src/svd.rs:150-163): pivoted QR of diag(S) Vt, Q = U Q_b. */
+rc_status rc_svd_to_qr_f64(rc_context *ctx, rc_matrix u, const double *s, rc_matrix vt, rc_matrix q, rc_matrix r, int64_t *ind);
+rc_status rc_svd_to_qr_f32(rc_context *ctx, rc_matrix u, const float *s, rc_matrix vt, rc_matrix q, rc_matrix r, int64_t *ind);
+/* SVDTraits::compute_from_range_estimate (src/svd.rs:171-183): u: m x r', s: r', vt: r' x n. */
+rc_status rc_svd_from_range_estimate_f64(rc_context *ctx, rc_matrix range, rc_matrix a, rc_matrix u, double *s, rc_matrix vt);
+rc_status rc_svd_from_range_estimate_f32(rc_context *ctx, rc_matrix range, rc_matrix a, rc_matrix u, float *s, rc_matrix vt);
+
+/* ------------------------------- col_interp_decomp.rs / row_interp_decomp.rs -- */
+/* ColumnIDTraits::two_sided_id (src/col_interp_decomp.rs:116-125): from C (m x k)
+ * computes the row ID of C: c_out: m x k (= row_id.x), x: k x k (= row_id.r), row_ind: m.
+ * (r = Z and col_ind are carried over unchanged by the caller.) */
+rc_status rc_column_id_two_sided_f64(rc_context *ctx, rc_matrix c, rc_matrix c_out, rc_matrix x, int64_t *row_ind);
+rc_status rc_column_id_two_sided_f32(rc_context *ctx, rc_matrix c, rc_matrix c_out, rc_matrix x, int64_t *row_ind);
+/* RowIDTraits::two_sided_id (src/row_interp_decomp.rs:120-130): from R (k x n)
+ * computes the column ID of R: x: k x k (= col_id.c), r_out: k x n (= col_id.z), col_ind: n. */
+rc_status rc_row_id_two_sided_f64(rc_context *ctx, rc_matrix r, rc_matrix x, rc_matrix r_out, int64_t *col_ind);
+rc_status rc_row_id_two_sided_f32(rc_context *ctx, rc_matrix r, rc_matrix x, rc_matrix r_out, int64_t *col_ind);
+
+/* ------------------------------------------------------ random_sampling.rs -- */
+/* MaxColNorm::max_col_norm (src/random_sampling.rs:184-191). Synchronous, host scalar out. */
+rc_status rc_max_col_norm_f64(rc_context *ctx, rc_matrix y, double *out);
+rc_status rc_max_col_norm_f32(rc_context *ctx, rc_matrix y, float *out);
+/* SampleRange::sample_range_by_rank (src/random_sampling.rs:103-118):
+ * q: m x k = first k columns of Q in the pivoted QR of A Omega, Omega: n x (k+p).
+ * omega.data == NULL => Omega is generated on the device from (seed, offset 0). */
+rc_status rc_sample_range_by_rank_f64(rc_context *ctx, rc_matrix a, int64_t k, int64_t p, rc_matrix omega, uint64_t seed, rc_matrix q);
+rc_status rc_sample_range_by_rank_f32(rc_context *ctx, rc_matrix a, int64_t k, int64_t p, rc_matrix omega, uint64_t seed, rc_matrix q);
+/* SampleRangePowerIteration::sample_range_power_iteration (src/random_sampling.rs:131-160),
+ * INCLUDING its variable-shadowing quirk: for it_count >= 1 exactly one power
+ * step survives. */
+rc_status rc_sample_range_power_iteration_f64(rc_context *ctx, rc_matrix a, int64_t k, int64_t p, int64_t it_count, rc_matrix omega, uint64_t seed, rc_matrix q);
+rc_status rc_sample_range_power_iteration_f32(rc_context *ctx, rc_matrix a, int64_t k, int64_t p, int64_t it_count, rc_matrix omega, uint64_t seed, rc_matrix q);
+/* AdaptiveSampling::sample_range_adaptive (src/random_sampling.rs:223-274).
+ *   q_cap: m x cap output buffer; on return the basis is its first *rank columns.
+ *   omegas: n x (sample_size * blocks) explicit Gaussian blocks consumed left to
+ *           right (data == NULL => generated on device from seed).
+ *   hist_rank / hist_res (host, hist_cap entries): the residual history
+ *           Vec<(usize, f64)>; *hist_len entries are written.
+ * Returns RC_COMPRESSION_ERROR if cap columns (or the explicit Omega blocks) are
+ * exhausted before the tolerance is met.  Synchronous (the loop condition is a host scalar). */
+rc_status rc_sample_range_adaptive_f64(rc_context *ctx, rc_matrix a, double rel_tol, int64_t sample_size, rc_matrix omegas, uint64_t seed, rc_matrix q_cap, int64_t *rank, int64_t *hist_rank, double *hist_res, int64_t hist_cap, int64_t *hist_len);
+rc_status rc_sample_range_adaptive_f32(rc_context *ctx, rc_matrix a, double rel_tol, int64_t sample_size, rc_matrix omegas, uint64_t seed, rc_matrix q_cap, int64_t *rank, int64_t *hist_rank, double *hist_res, int64_t hist_cap, int64_t *hist_len);
+
+/* ------------------------------------------------ fused pipeline (bench) -- */
+/* cfg3 "rSVD + ID" in one call, no host synchronisation inside (capturable in
+ * a hipGraph): sample_range_by_rank -> SVD::compute_from_range_estimate ->
+ * QR::compute_from_range_estimate -> column_id, sharing B = Q^H A between the
+ * two range-estimate consumers (identical results to calling them one by one).
+ * Any output with data == NULL is skipped; id outputs all NULL => rSVD only. */
+typedef struct rc_rsvd_id_out {
+    rc_matrix range_q; /* m x k   */
+    rc_matrix u;       /* m x k   */
+    void *s;           /* k       */
+    rc_matrix vt;      /* k x n   */
+    rc_matrix qr_q;    /* m x k   */
+    rc_matrix qr_r;    /* k x n   */
+    int64_t *qr_ind;   /* n       */
+    rc_matrix id_c;    /* m x k   */
+    rc_matrix id_z;    /* k x n   */
+} rc_rsvd_id_out;
+rc_status rc_rsvd_id_f64(rc_context *ctx, rc_matrix a, int64_t k, int64_t p, rc_matrix omega, uint64_t seed, const rc_rsvd_id_out *out);
+rc_status rc_rsvd_id_f32(rc_context *ctx, rc_matrix a, int64_t k, int64_t p, rc_matrix omega, uint64_t seed, const rc_rsvd_id_out *out);
+
+/* cfg5 unit of work: rank-k column ID of one dense matrix,
+ * QR::compute_from -> compress(RANK(k)) -> column_id
+ * (examples/interpolative_decomposition.rs:25-32) with the truncated
+ * factorization (see rc_pivoted_qr).  c: m x k, z: k x n, col_ind: n. */
+rc_status rc_column_id_rank_f64(rc_context *ctx, rc_matrix a, int64_t k, rc_matrix c, rc_matrix z, int64_t *col_ind);
+rc_status rc_column_id_rank_f32(rc_context *ctx, rc_matrix a, int64_t k, rc_matrix c, rc_matrix z, int64_t *col_ind);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RUSTY_COMPRESSION_AMD_H */

@@ -1,0 +1,409 @@
+// Householder QR with column pivoting, form-Q and triangular solves for gfx950.
+//
+// Replaces LAPACK ?geqp3 (+ ?laqp2 / ?larfg), ?orgqr and ?trtrs as the
+// reference reaches them:
+//   /root/reference/src/pivoted_qr.rs:139-150, :161-172   (?geqp3)
+//   /root/reference/src/pivoted_qr.rs:104-108             (?orgqr via lax::Lapack::q)
+//   /root/reference/src/qr.rs:290-301, :384-395           (?trtrs per column / per row)
+//
+// Numerical contract (what makes the permutation reproducible): ?laqp2
+// semantics -- pivot = FIRST maximum of the partial column norms (idamax),
+// reflector with beta = -sign(alpha) * hypot(alpha, |x|), partial norms
+// down-dated with the LAPACK formula and recomputed from scratch when
+// temp2 <= sqrt(eps) (tol3z).
+//
+// MI355X mapping.  The m x n working matrix is column-major and columns are
+// never moved: `jpvt` maps factorization position -> physical column, so a
+// "swap" is two index writes.  Reflector application is independent per column,
+// so the trailing update is column-parallel (one wave or one workgroup per
+// column, the column held in registers between the dot product and the update:
+// one read + one write of the trailing matrix per step, nothing else); the only
+// serial piece per step is the single-workgroup pivot search + reflector
+// generation.
+#include "rc_common.hpp"
+
+namespace rc {
+
+static __host__ __device__ inline int64_t cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+template <typename T> struct Num;
+template <> struct Num<double> {
+    static __host__ __device__ inline double tol3z() { return 1.0536712127723509e-08; }  // sqrt(2^-53)
+};
+template <> struct Num<float> {
+    static __host__ __device__ inline float tol3z() { return 2.44140625e-04f; }  // sqrt(2^-24)
+};
+
+template <typename T>
+__device__ inline T wsum(T v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+
+// sum over a group of TPC threads (TPC = 64: one wave; TPC = 256: the 4-wave workgroup)
+template <typename T, int TPC>
+__device__ inline T group_sum(T v, T *sh /* 4 entries, TPC == 256 only */) {
+    v = wsum(v);
+    if (TPC == 256) {
+        __syncthreads();
+        if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
+        __syncthreads();
+        v = sh[0] + sh[1] + sh[2] + sh[3];
+    }
+    return v;
+}
+
+// ---------------------------------------------------------------------------
+// init: jpvt = iota, vn1 = vn2 = column norms
+// ---------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void k_qr_init(Mat<T> w, int pivot, int64_t *jpvt, T *vn1, T *vn2) {
+    __shared__ T sh[4];
+    for (int64_t j = blockIdx.x; j < w.cols; j += gridDim.x) {
+        if (pivot) {
+            const T *col = w.p + j * w.cs;
+            T acc = 0;
+            for (int64_t i = threadIdx.x; i < w.rows; i += 256) { T v = col[i]; acc += v * v; }
+            acc = group_sum<T, 256>(acc, sh);
+            if (threadIdx.x == 0) { T nrm = sqrt(acc); vn1[j] = nrm; vn2[j] = nrm; }
+        }
+        if (threadIdx.x == 0) jpvt[j] = j;
+    }
+}
+
+// ---------------------------------------------------------------------------
+// step j, serial part: pivot search + "swap" + reflector generation (?larfg)
+// ---------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(1024) void k_qr_pivot_reflect(Mat<T> w, int64_t j, int pivot, int64_t *jpvt, T *vn1, T *vn2, T *tau) {
+    __shared__ T shv[16];
+    __shared__ long long shi[16];
+    __shared__ T shs[16];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int64_t n = w.cols, m = w.rows;
+    if (pivot) {
+        T best = (T)-1;
+        long long bi = 0x7fffffffffffffffLL;
+        for (int64_t p = j + tid; p < n; p += 1024) {
+            T v = fabs(vn1[p]);
+            if (v > best) { best = v; bi = p; }
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            T ob = __shfl_xor(best, off, 64);
+            long long oi = __shfl_xor(bi, off, 64);
+            if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
+        }
+        if (lane == 0) { shv[wv] = best; shi[wv] = bi; }
+        __syncthreads();
+        if (tid == 0) {
+            for (int k = 1; k < 16; ++k)
+                if (shv[k] > best || (shv[k] == best && shi[k] < bi)) { best = shv[k]; bi = shi[k]; }
+            int64_t pvt = (bi >= j && bi < n) ? (int64_t)bi : j;
+            if (pvt != j) {  // dlaqp2: swap columns (here: indices), carry the norms of position j to pvt
+                int64_t t = jpvt[pvt]; jpvt[pvt] = jpvt[j]; jpvt[j] = t;
+                vn1[pvt] = vn1[j];
+                vn2[pvt] = vn2[j];
+            }
+        }
+        __syncthreads();
+    }
+    // ---- ?larfg on column jpvt[j], rows j..m-1 -------------------------------
+    T *col = w.p + jpvt[j] * w.cs;
+    const T alpha = col[j];
+    T acc = 0;
+    for (int64_t i = j + 1 + tid; i < m; i += 1024) { T v = col[i]; acc += v * v; }
+    acc = wsum(acc);
+    if (lane == 0) shs[wv] = acc;
+    __syncthreads();  // also orders every thread's read of alpha before the write of beta below
+    T ssq = 0;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) ssq += shs[k];
+    const T xnorm = sqrt(ssq);
+    if (xnorm == (T)0) {
+        if (tid == 0) tau[j] = 0;  // H = I
+        return;
+    }
+    const T beta = -copysign(hypot(alpha, xnorm), alpha);
+    const T scal = (T)1 / (alpha - beta);
+    for (int64_t i = j + 1 + tid; i < m; i += 1024) col[i] *= scal;
+    if (tid == 0) {
+        tau[j] = (beta - alpha) / beta;
+        col[j] = beta;
+    }
+}
+
+// ---------------------------------------------------------------------------
+// step j, parallel part: apply H_j to every remaining column and down-date its
+// partial norm.  TPC threads per column; the column segment lives in registers
+// (MAXE elements per thread) between the dot product and the update.
+// ---------------------------------------------------------------------------
+template <typename T, int TPC, int MAXE>
+__global__ __launch_bounds__(256) void k_qr_apply(Mat<T> w, int64_t j, int pivot, const int64_t *jpvt, T *vn1, T *vn2, const T *tau) {
+    __shared__ T sh[4];
+    __shared__ T shx;
+    constexpr int CPW = 256 / TPC;
+    const int lt = threadIdx.x % TPC;
+    const int64_t n = w.cols, m = w.rows;
+    const int64_t p = j + 1 + (int64_t)blockIdx.x * CPW + threadIdx.x / TPC;
+    const bool active = p < n;
+    if (TPC == 64 && !active) return;  // whole wave idle: no barrier is used on this path
+    const T tj = tau[j];
+    const T *vcol = w.p + jpvt[j] * w.cs;
+    T *xcol = w.p + jpvt[active ? p : j] * w.cs;
+
+    T x[MAXE], v[MAXE];
+    T dot = 0;
+#pragma unroll
+    for (int e = 0; e < MAXE; ++e) {
+        int64_t i = j + lt + (int64_t)e * TPC;
+        x[e] = 0; v[e] = 0;
+        if (i < m) {
+            x[e] = xcol[i];
+            v[e] = (i == j) ? (T)1 : vcol[i];
+            dot += v[e] * x[e];
+        }
+    }
+    if (tj != (T)0) {  // tau == 0: H = I (dlarf skips the update)
+        dot = group_sum<T, TPC>(dot, sh);
+        const T f = tj * dot;
+#pragma unroll
+        for (int e = 0; e < MAXE; ++e) {
+            int64_t i = j + lt + (int64_t)e * TPC;
+            if (i < m) { x[e] -= f * v[e]; xcol[i] = x[e]; }
+        }
+    }
+    if (!pivot) return;
+    // ---- partial-norm down-date (dlaqp2) --------------------------------------
+    T xj;
+    if (TPC == 64) {
+        xj = __shfl(x[0], 0, 64);
+    } else {
+        __syncthreads();
+        if (threadIdx.x == 0) shx = x[0];
+        __syncthreads();
+        xj = shx;
+    }
+    const T vn = vn1[p];
+    if (vn != (T)0) {
+        T t = fabs(xj) / vn;
+        T temp = (T)1 - t * t;
+        temp = temp > (T)0 ? temp : (T)0;
+        T r = vn / vn2[p];
+        T temp2 = temp * r * r;
+        if (temp2 <= Num<T>::tol3z()) {
+            T ss = 0;
+#pragma unroll
+            for (int e = 0; e < MAXE; ++e) {
+                int64_t i = j + lt + (int64_t)e * TPC;
+                if (i > j && i < m) ss += x[e] * x[e];
+            }
+            ss = group_sum<T, TPC>(ss, sh);
+            if (lt == 0) { T nn = (j < m - 1) ? sqrt(ss) : (T)0; vn1[p] = nn; vn2[p] = nn; }
+        } else if (lt == 0) {
+            vn1[p] = vn * sqrt(temp);
+        }
+    }
+}
+
+// general fallback: any column length, two passes over memory (256 threads per column)
+template <typename T>
+__global__ __launch_bounds__(256) void k_qr_apply_general(Mat<T> w, int64_t j, int pivot, const int64_t *jpvt, T *vn1, T *vn2, const T *tau) {
+    __shared__ T sh[4];
+    const int64_t n = w.cols, m = w.rows;
+    const int64_t p = j + 1 + blockIdx.x;
+    if (p >= n) return;
+    const T tj = tau[j];
+    const T *vcol = w.p + jpvt[j] * w.cs;
+    T *xcol = w.p + jpvt[p] * w.cs;
+    if (tj != (T)0) {
+        T dot = 0;
+        for (int64_t i = j + threadIdx.x; i < m; i += 256) dot += ((i == j) ? (T)1 : vcol[i]) * xcol[i];
+        dot = group_sum<T, 256>(dot, sh);
+        const T f = tj * dot;
+        for (int64_t i = j + threadIdx.x; i < m; i += 256) xcol[i] -= f * ((i == j) ? (T)1 : vcol[i]);
+    }
+    if (!pivot) return;
+    __syncthreads();  // row j was written by thread 0 of this workgroup
+    const T xj = xcol[j];
+    const T vn = vn1[p];
+    if (vn != (T)0) {
+        T t = fabs(xj) / vn;
+        T temp = (T)1 - t * t;
+        temp = temp > (T)0 ? temp : (T)0;
+        T r = vn / vn2[p];
+        T temp2 = temp * r * r;
+        if (temp2 <= Num<T>::tol3z()) {
+            T ss = 0;
+            for (int64_t i = j + 1 + threadIdx.x; i < m; i += 256) { T v = xcol[i]; ss += v * v; }
+            ss = group_sum<T, 256>(ss, sh);
+            if (threadIdx.x == 0) { T nn = (j < m - 1) ? sqrt(ss) : (T)0; vn1[p] = nn; vn2[p] = nn; }
+        } else if (threadIdx.x == 0) {
+            vn1[p] = vn * sqrt(temp);
+        }
+    }
+}
+
+template <typename T>
+void geqp3_inplace(rc_context *c, Mat<T> w, int64_t kmax, bool pivot, int64_t *jpvt, T *tau, T *vn) {
+    RC_REQUIRE(w.rs == 1, RC_LAYOUT_ERROR, "geqp3: working matrix must be column-major");
+    const int64_t m = w.rows, n = w.cols;
+    if (m == 0 || n == 0) return;
+    kmax = std::min(kmax, std::min(m, n));
+    T *vn1 = vn, *vn2 = vn + n;
+    const int pv = pivot ? 1 : 0;
+    hipLaunchKernelGGL(k_qr_init<T>, dim3((unsigned)std::min<int64_t>(n, 65535)), dim3(256), 0, c->stream, w, pv, jpvt, vn1, vn2);
+    for (int64_t j = 0; j < kmax; ++j) {
+        hipLaunchKernelGGL(k_qr_pivot_reflect<T>, dim3(1), dim3(1024), 0, c->stream, w, j, pv, jpvt, vn1, vn2, tau);
+        const int64_t rem_cols = n - j - 1;
+        if (rem_cols <= 0) continue;
+        const int64_t rem = m - j;
+        const int64_t c64 = cdiv(rem, 64), c256 = cdiv(rem, 256);
+#define RC_APPLY(TPC, MAXE)                                                                                       \
+    hipLaunchKernelGGL((k_qr_apply<T, TPC, MAXE>), dim3((unsigned)cdiv(rem_cols, 256 / TPC)), dim3(256), 0,      \
+                       c->stream, w, j, pv, jpvt, vn1, vn2, tau)
+        if (c64 <= 2) RC_APPLY(64, 2);
+        else if (c64 <= 8) RC_APPLY(64, 8);
+        else if (c256 <= 8) RC_APPLY(256, 8);
+        else if (c256 <= 32) RC_APPLY(256, 32);
+        else
+            hipLaunchKernelGGL(k_qr_apply_general<T>, dim3((unsigned)rem_cols), dim3(256), 0, c->stream, w, j, pv, jpvt, vn1, vn2, tau);
+#undef RC_APPLY
+    }
+}
+
+// ---------------------------------------------------------------------------
+// R extraction: r(i, p) = (i <= p) ? w(i, jpvt[p]) : 0   (?geqp3 output upper
+// trapezoid in position order; IntoTriangular, pivoted_qr.rs:100-102)
+// ---------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void k_extract_r(Mat<T> w, const int64_t *jpvt, Mat<T> r) {
+    const bool col_fast = (r.cs <= r.rs);
+    const int64_t total = r.rows * r.cols;
+    for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+        int64_t i, p;
+        if (col_fast) { i = e / r.cols; p = e - i * r.cols; }
+        else { p = e / r.rows; i = e - p * r.rows; }
+        r.at(i, p) = (i <= p) ? w.p[jpvt[p] * w.cs + i] : (T)0;
+    }
+}
+template <typename T>
+void extract_r(rc_context *c, Mat<T> w, const int64_t *jpvt, Mat<T> r) {
+    if (r.empty()) return;
+    int grid = (int)std::min<int64_t>(cdiv(r.rows * r.cols, 256), 8192);
+    hipLaunchKernelGGL(k_extract_r<T>, dim3(grid), dim3(256), 0, c->stream, w, jpvt, r);
+}
+
+// ---------------------------------------------------------------------------
+// form Q (?org2r semantics): column cq of Q = H_0 ... H_{k-1} e_cq; for e_cq
+// only H_j with j <= cq act non-trivially, so each output column is an
+// independent chain -> one workgroup per column, column in registers.
+// ---------------------------------------------------------------------------
+template <typename T, int MAXE>
+__global__ __launch_bounds__(256) void k_form_q(Mat<T> w, const int64_t *jpvt, const T *tau, int64_t k, Mat<T> qw) {
+    __shared__ T sh[4];
+    const int64_t m = w.rows;
+    const int64_t cq = blockIdx.x;
+    const int tid = threadIdx.x;
+    T x[MAXE];
+#pragma unroll
+    for (int e = 0; e < MAXE; ++e) {
+        int64_t i = tid + (int64_t)e * 256;
+        x[e] = (i == cq) ? (T)1 : (T)0;
+    }
+    for (int64_t j = (cq < k - 1 ? cq : k - 1); j >= 0; --j) {
+        const T tj = tau[j];
+        if (tj == (T)0) continue;
+        const T *vcol = w.p + jpvt[j] * w.cs;
+        T v[MAXE];
+        T dot = 0;
+#pragma unroll
+        for (int e = 0; e < MAXE; ++e) {
+            int64_t i = tid + (int64_t)e * 256;
+            v[e] = 0;
+            if (i < m && i >= j) {
+                v[e] = (i == j) ? (T)1 : vcol[i];
+                dot += v[e] * x[e];
+            }
+        }
+        dot = group_sum<T, 256>(dot, sh);
+        const T f = tj * dot;
+#pragma unroll
+        for (int e = 0; e < MAXE; ++e) x[e] -= f * v[e];
+    }
+    T *out = qw.p + cq * qw.cs;
+#pragma unroll
+    for (int e = 0; e < MAXE; ++e) {
+        int64_t i = tid + (int64_t)e * 256;
+        if (i < m) out[i] = x[e];
+    }
+}
+// general: the column lives in global memory (qw), any m
+template <typename T>
+__global__ __launch_bounds__(256) void k_form_q_general(Mat<T> w, const int64_t *jpvt, const T *tau, int64_t k, Mat<T> qw) {
+    __shared__ T sh[4];
+    const int64_t m = w.rows;
+    const int64_t cq = blockIdx.x;
+    const int tid = threadIdx.x;
+    T *x = qw.p + cq * qw.cs;
+    for (int64_t i = tid; i < m; i += 256) x[i] = (i == cq) ? (T)1 : (T)0;
+    for (int64_t j = (cq < k - 1 ? cq : k - 1); j >= 0; --j) {
+        const T tj = tau[j];
+        if (tj == (T)0) continue;
+        const T *vcol = w.p + jpvt[j] * w.cs;
+        T dot = 0;
+        for (int64_t i = j + tid; i < m; i += 256) dot += ((i == j) ? (T)1 : vcol[i]) * x[i];  // same thread wrote x[i]
+        dot = group_sum<T, 256>(dot, sh);
+        const T f = tj * dot;
+        for (int64_t i = j + tid; i < m; i += 256) x[i] -= f * ((i == j) ? (T)1 : vcol[i]);
+    }
+}
+
+template <typename T>
+void form_q(rc_context *c, Mat<T> w, const int64_t *jpvt, const T *tau, int64_t k, Mat<T> qw) {
+    RC_REQUIRE(w.rs == 1 && qw.rs == 1 && qw.rows == w.rows, RC_LAYOUT_ERROR, "form_q: column-major operands required");
+    if (qw.empty()) return;
+    const int64_t m = w.rows;
+    const unsigned grid = (unsigned)qw.cols;
+    if (k <= 0) { fill_identity(c, qw); return; }
+    if (m <= 256 * 2) hipLaunchKernelGGL((k_form_q<T, 2>), dim3(grid), dim3(256), 0, c->stream, w, jpvt, tau, k, qw);
+    else if (m <= 256 * 8) hipLaunchKernelGGL((k_form_q<T, 8>), dim3(grid), dim3(256), 0, c->stream, w, jpvt, tau, k, qw);
+    else if (m <= 256 * 32) hipLaunchKernelGGL((k_form_q<T, 32>), dim3(grid), dim3(256), 0, c->stream, w, jpvt, tau, k, qw);
+    else hipLaunchKernelGGL(k_form_q_general<T>, dim3(grid), dim3(256), 0, c->stream, w, jpvt, tau, k, qw);
+}
+
+// ---------------------------------------------------------------------------
+// T X = B, T upper triangular k x k (any strides), B k x nrhs in place.
+// One thread per right-hand side; consecutive threads take consecutive RHS so
+// the accesses coalesce when B is row-major (k x nrhs, the Z / X^T blocks).
+// Replaces the reference's per-column ?trtrs loop (qr.rs:290-301, :384-395).
+// ---------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void k_trsm_upper(Mat<T> t, Mat<T> b) {
+    const int64_t col = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (col >= b.cols) return;
+    const int64_t k = t.rows;
+    for (int64_t i = k - 1; i >= 0; --i) {
+        T s = b.at(i, col);
+        for (int64_t jj = i + 1; jj < k; ++jj) s -= t.at(i, jj) * b.at(jj, col);
+        b.at(i, col) = s / t.at(i, i);
+    }
+}
+template <typename T>
+void trsm_upper(rc_context *c, Mat<T> t, Mat<T> b) {
+    RC_REQUIRE(t.rows == t.cols && t.rows == b.rows, RC_INVALID_ARGUMENT, "trsm: shape mismatch");
+    if (b.empty()) return;
+    hipLaunchKernelGGL(k_trsm_upper<T>, dim3((unsigned)cdiv(b.cols, 256)), dim3(256), 0, c->stream, t, b);
+}
+
+#define RC_INST(T)                                                                                         \
+    template void geqp3_inplace<T>(rc_context *, Mat<T>, int64_t, bool, int64_t *, T *, T *);             \
+    template void extract_r<T>(rc_context *, Mat<T>, const int64_t *, Mat<T>);                             \
+    template void form_q<T>(rc_context *, Mat<T>, const int64_t *, const T *, int64_t, Mat<T>);           \
+    template void trsm_upper<T>(rc_context *, Mat<T>, Mat<T>);
+RC_INST(double)
+RC_INST(float)
+#undef RC_INST
+
+}  // namespace rc

@@ -1,0 +1,789 @@
+// C ABI of librusty_compression_amd + the host-side composition of the hot path.
+// Every exported function cites (in include/rusty_compression_amd.h) the
+// reference trait method it replaces; the compositions below follow the
+// reference's call sequences with GEMMs instead of gemv
+// loops and one batched triangular solve instead of per-column ?trtrs calls.
+#include "rc_common.hpp"
+
+#include <algorithm>
+#include <cmath>
+
+using namespace rc;
+
+// ===========================================================================
+// context / arena
+// ===========================================================================
+static constexpr size_t kAlign = 256;
+
+void rc_context::reset_arena() {
+    if (!overflow.empty()) {
+        // the previous call outgrew the arena: rebuild it once, big enough
+        (void)hipStreamSynchronize(stream);
+        for (void *p : overflow) (void)hipFree(p);
+        overflow.clear();
+        size_t want = arena_high + arena_high / 4 + (1u << 20);
+        if (arena) (void)hipFree(arena);
+        arena = nullptr;
+        arena_size = 0;
+        if (hipMalloc(reinterpret_cast<void **>(&arena), want) == hipSuccess) arena_size = want;
+    }
+    arena_off = 0;
+    arena_high = 0;
+}
+
+void *rc_context::alloc_bytes(size_t bytes) {
+    bytes = (bytes + kAlign - 1) / kAlign * kAlign;
+    if (bytes == 0) bytes = kAlign;
+    void *p = nullptr;
+    if (arena_off + bytes <= arena_size) {
+        p = arena + arena_off;
+    } else {
+        // not capturable in a hipGraph: warm the context up with one eager call first
+        RC_HIP(hipMalloc(&p, bytes));
+        overflow.push_back(p);
+    }
+    arena_off += bytes;
+    arena_high = std::max(arena_high, arena_off);
+    return p;
+}
+
+void rc_context::reserve(size_t bytes) {
+    if (bytes <= arena_size) return;
+    RC_HIP(hipStreamSynchronize(stream));
+    if (arena) RC_HIP(hipFree(arena));
+    arena = nullptr;
+    arena_size = 0;
+    RC_HIP(hipMalloc(reinterpret_cast<void **>(&arena), bytes));
+    arena_size = bytes;
+}
+
+void rc_context::release_all() {
+    (void)hipStreamSynchronize(stream);
+    for (void *p : overflow) (void)hipFree(p);
+    overflow.clear();
+    if (arena) (void)hipFree(arena);
+    arena = nullptr;
+    arena_size = 0;
+    if (pinned) (void)hipHostFree(pinned);
+    pinned = nullptr;
+}
+
+namespace {
+
+struct DeviceGuard {
+    int prev = -1;
+    explicit DeviceGuard(int dev) {
+        (void)hipGetDevice(&prev);
+        if (prev != dev) (void)hipSetDevice(dev);
+        else prev = -1;
+    }
+    ~DeviceGuard() { if (prev >= 0) (void)hipSetDevice(prev); }
+};
+
+template <typename F>
+rc_status guarded(rc_context *ctx, F &&f) {
+    if (!ctx) return RC_INVALID_ARGUMENT;
+    DeviceGuard dg(ctx->device);
+    try {
+        ctx->reset_arena();
+        f();
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) fail(RC_RUNTIME_ERROR, "kernel launch failed: %s", hipGetErrorString(e));
+        return RC_OK;
+    } catch (const Error &e) {
+        ctx->last_error = e.msg;
+        return e.code;
+    } catch (const std::exception &e) {
+        ctx->last_error = e.what();
+        return RC_RUNTIME_ERROR;
+    }
+}
+
+// small device -> host read-back through the pinned buffer (synchronises the stream)
+template <typename T>
+void read_back(rc_context *c, const T *dev, T *host, size_t n) {
+    size_t bytes = n * sizeof(T);
+    if (c->pinned_size < bytes) {
+        if (c->pinned) RC_HIP(hipHostFree(c->pinned));
+        c->pinned = nullptr;
+        c->pinned_size = 0;
+        size_t want = std::max<size_t>(bytes, 1 << 16);
+        RC_HIP(hipHostMalloc(&c->pinned, want, hipHostMallocDefault));
+        c->pinned_size = want;
+    }
+    RC_HIP(hipMemcpyAsync(c->pinned, dev, bytes, hipMemcpyDeviceToHost, c->stream));
+    RC_HIP(hipStreamSynchronize(c->stream));
+    std::memcpy(host, c->pinned, bytes);
+}
+
+template <typename T>
+Mat<T> tmp_colmajor(rc_context *c, int64_t rows, int64_t cols) {
+    int64_t ld = std::max<int64_t>(rows, 1);
+    return colmajor(c->alloc<T>((size_t)ld * std::max<int64_t>(cols, 1)), rows, cols, ld);
+}
+template <typename T>
+Mat<T> tmp_rowmajor(rc_context *c, int64_t rows, int64_t cols) {
+    int64_t ld = std::max<int64_t>(cols, 1);
+    return rowmajor(c->alloc<T>((size_t)ld * std::max<int64_t>(rows, 1)), rows, cols, ld);
+}
+
+void check_view(const rc_matrix &m, const char *name, bool allow_null = false) {
+    RC_REQUIRE(m.rows >= 0 && m.cols >= 0, RC_INVALID_ARGUMENT, "%s: negative extent", name);
+    if (!allow_null) RC_REQUIRE(m.data != nullptr || m.rows == 0 || m.cols == 0, RC_INVALID_ARGUMENT, "%s: null data", name);
+}
+
+// ===========================================================================
+// compositions (templated on the scalar type)
+// ===========================================================================
+
+// Pivoted QR of the column-major working matrix w (destroyed).
+//   q: m x k (may be empty to skip), r: k x n (may be empty), ind: n, k <= min(m, n)
+template <typename T>
+void qrcp_core(rc_context *c, Mat<T> w, int64_t k, bool pivot, Mat<T> q, Mat<T> r, int64_t *ind) {
+    const int64_t n = w.cols;
+    ArenaMark mark(c);
+    T *tau = c->alloc<T>((size_t)std::max<int64_t>(k, 1));
+    T *vn = c->alloc<T>((size_t)std::max<int64_t>(2 * n, 1));
+    geqp3_inplace(c, w, k, pivot, ind, tau, vn);
+    if (!r.empty()) extract_r(c, w, ind, r);
+    if (!q.empty()) {
+        if (q.rs == 1 && q.cs >= q.rows) {
+            form_q(c, w, ind, tau, k, q);
+        } else {
+            Mat<T> qw = tmp_colmajor<T>(c, w.rows, q.cols);
+            form_q(c, w, ind, tau, k, qw);
+            copy_mat(c, qw, q);
+        }
+    }
+}
+
+// PivotedQR::pivoted_qr  (/root/reference/src/pivoted_qr.rs:25-31, :81-119)
+template <typename T>
+void pivoted_qr(rc_context *c, Mat<T> a, Mat<T> q, Mat<T> r, int64_t *ind) {
+    const int64_t m = a.rows, n = a.cols, k = q.cols;
+    RC_REQUIRE(q.rows == m && r.cols == n && r.rows == k, RC_INVALID_ARGUMENT,
+               "pivoted_qr: a %lld x %lld, q %lld x %lld, r %lld x %lld", (long long)m, (long long)n, (long long)q.rows,
+               (long long)q.cols, (long long)r.rows, (long long)r.cols);
+    RC_REQUIRE(k <= std::min(m, n), RC_INVALID_ARGUMENT, "pivoted_qr: rank %lld exceeds min(m, n)", (long long)k);
+    if (n == 0) return;
+    ArenaMark mark(c);
+    Mat<T> w = tmp_colmajor<T>(c, m, n);  // the reference's F-order working copy (pivoted_qr.rs:28-29)
+    copy_mat(c, a, w);
+    qrcp_core(c, w, k, true, q, r, ind);
+}
+
+// ComputeSVD::compute_svd on a working matrix: wt is the TALL orientation
+// (M x r column-major, destroyed), i.e. a itself when m >= n, a^T otherwise.
+template <typename T>
+void svd_core(rc_context *c, Mat<T> wt, bool transposed, Mat<T> u, T *s, Mat<T> vt) {
+    const int64_t M = wt.rows, r = wt.cols;
+    ArenaMark mark(c);
+    int64_t *jp = c->alloc<int64_t>((size_t)std::max<int64_t>(r, 1));
+    T *tau = c->alloc<T>((size_t)std::max<int64_t>(r, 1));
+    T *vn = c->alloc<T>((size_t)std::max<int64_t>(2 * r, 1));
+    geqp3_inplace(c, wt, r, false, jp, tau, vn);
+    Mat<T> core = tmp_colmajor<T>(c, r, r);
+    // tall: core = R ; wide: core = L = R^T  (a = L Q_w^T)
+    extract_r(c, wt, jp, transposed ? core.t() : core);
+    Mat<T> qw = tmp_colmajor<T>(c, M, r);
+    form_q(c, wt, jp, tau, r, qw);
+    Mat<T> vwork = tmp_colmajor<T>(c, r, r), uc = tmp_colmajor<T>(c, r, r), vc = tmp_colmajor<T>(c, r, r);
+    jacobi_svd(c, core, vwork, uc, s, vc);
+    if (!transposed) {
+        // a = Q_w R = (Q_w Uc) S Vc^T
+        gemm<T>(c, 1, qw, uc, 0, u);
+        copy_mat(c, vc.t(), vt);
+    } else {
+        // a = L Q_w^T = Uc S (Q_w Vc)^T
+        copy_mat(c, uc, u);
+        gemm<T>(c, 1, vc.t(), qw.t(), 0, vt);
+    }
+}
+
+// /root/reference/src/compute_svd.rs:18-27
+template <typename T>
+void compute_svd(rc_context *c, Mat<T> a, Mat<T> u, T *s, Mat<T> vt) {
+    const int64_t m = a.rows, n = a.cols, r = std::min(m, n);
+    RC_REQUIRE(u.rows == m && u.cols == r && vt.rows == r && vt.cols == n, RC_INVALID_ARGUMENT,
+               "compute_svd: a %lld x %lld needs u %lld x %lld, vt %lld x %lld", (long long)m, (long long)n, (long long)m,
+               (long long)r, (long long)r, (long long)n);
+    if (r == 0) return;
+    ArenaMark mark(c);
+    const bool transposed = m < n;
+    Mat<T> src = transposed ? a.t() : a;
+    Mat<T> wt = tmp_colmajor<T>(c, src.rows, src.cols);
+    copy_mat(c, src, wt);
+    svd_core(c, wt, transposed, u, s, vt);
+}
+
+// QRTraits::column_id  (/root/reference/src/qr.rs:270-309)
+template <typename T>
+void qr_column_id(rc_context *c, Mat<T> q, Mat<T> r, const int64_t *ind, Mat<T> cm, Mat<T> z) {
+    const int64_t m = q.rows, k = q.cols, n = r.cols;
+    RC_REQUIRE(r.rows == k && cm.rows == m && cm.cols == k && z.rows == k && z.cols == n, RC_INVALID_ARGUMENT,
+               "column_id: q %lld x %lld, r %lld x %lld, c %lld x %lld, z %lld x %lld", (long long)m, (long long)k,
+               (long long)r.rows, (long long)n, (long long)cm.rows, (long long)cm.cols, (long long)z.rows, (long long)z.cols);
+    RC_REQUIRE(k <= n, RC_INVALID_ARGUMENT, "column_id: rank exceeds the number of columns");
+    if (n == 0) return;
+    ArenaMark mark(c);
+    int64_t *inv = c->alloc<int64_t>((size_t)n);
+    invert_perm(c, ind, n, inv);
+    Mat<T> zt = tmp_rowmajor<T>(c, k, n);
+    if (k == n) {
+        // not rank deficient (qr.rs:274-281): C = Q R, Z = I with the COLINV permutation
+        gemm<T>(c, 1, q, r, 0, cm);
+        fill_identity(c, zt);
+    } else {
+        // Z = [I | R11^{-1} R12] (qr.rs:285-301, one batched solve), C = Q R11 (qr.rs:287-288)
+        fill_identity(c, zt.sub(0, k, 0, k));
+        copy_mat(c, r.sub(0, k, k, n - k), zt.sub(0, k, k, n - k));
+        trsm_upper(c, r.sub(0, k, 0, k), zt.sub(0, k, k, n - k));
+        gemm<T>(c, 1, q, r.sub(0, k, 0, k), 0, cm);
+    }
+    gather_cols(c, zt, inv, z);  // apply_permutation(ind, COLINV): out[:, i] = in[:, inv[i]]
+}
+
+// LQTraits::row_id (/root/reference/src/qr.rs:363-403) is the column ID of the
+// transposed factors: X = Z'^T, R_rows = C'^T with (C', Z') = column_id(Q^T, L^T).
+template <typename T>
+void lq_row_id(rc_context *c, Mat<T> l, Mat<T> q, const int64_t *ind, Mat<T> x, Mat<T> rrows) {
+    qr_column_id(c, q.t(), l.t(), ind, rrows.t(), x.t());
+}
+
+// B = range^H A written into `b` (any layout)
+template <typename T>
+void project(rc_context *c, Mat<T> range, Mat<T> a, Mat<T> b) {
+    gemm<T>(c, 1, range.t(), a, 0, b);
+}
+
+// QRTraits::compute_from_range_estimate (/root/reference/src/qr.rs:311-323)
+template <typename T>
+void qr_from_range(rc_context *c, Mat<T> range, Mat<T> a, Mat<T> q, Mat<T> r, int64_t *ind) {
+    const int64_t m = a.rows, n = a.cols, rr = range.cols, k = std::min(rr, n);
+    RC_REQUIRE(range.rows == m && q.rows == m && q.cols == k && r.rows == k && r.cols == n, RC_INVALID_ARGUMENT,
+               "qr_from_range_estimate: shape mismatch");
+    ArenaMark mark(c);
+    Mat<T> w = tmp_colmajor<T>(c, rr, n);
+    project(c, range, a, w);
+    Mat<T> qb = tmp_colmajor<T>(c, rr, k);
+    qrcp_core(c, w, k, true, qb, r, ind);
+    gemm<T>(c, 1, range, qb, 0, q);
+}
+
+// SVDTraits::compute_from_range_estimate (/root/reference/src/svd.rs:171-183)
+template <typename T>
+void svd_from_range(rc_context *c, Mat<T> range, Mat<T> a, Mat<T> u, T *s, Mat<T> vt) {
+    const int64_t m = a.rows, n = a.cols, rr = range.cols, r = std::min(rr, n);
+    RC_REQUIRE(range.rows == m && u.rows == m && u.cols == r && vt.rows == r && vt.cols == n, RC_INVALID_ARGUMENT,
+               "svd_from_range_estimate: shape mismatch");
+    ArenaMark mark(c);
+    Mat<T> ub = tmp_colmajor<T>(c, rr, r);
+    if (rr <= n) {
+        // B (rr x n, wide): its tall orientation B^T is column-major n x rr == B row-major
+        Mat<T> b = tmp_rowmajor<T>(c, rr, n);
+        project(c, range, a, b);
+        svd_core(c, b.t(), true, ub, s, vt);
+    } else {
+        Mat<T> b = tmp_colmajor<T>(c, rr, n);
+        project(c, range, a, b);
+        svd_core(c, b, false, ub, s, vt);
+    }
+    gemm<T>(c, 1, range, ub, 0, u);
+}
+
+// SampleRange::sample_range_by_rank (/root/reference/src/random_sampling.rs:103-118).
+// Only the first k Householder steps influence Q[:, :k], so the factorization stops there.
+template <typename T>
+void sample_range_by_rank(rc_context *c, Mat<T> a, int64_t k, int64_t p, Mat<T> omega, uint64_t seed, Mat<T> q) {
+    const int64_t m = a.rows, n = a.cols, l = k + p;
+    RC_REQUIRE(k >= 0 && p >= 0, RC_INVALID_ARGUMENT, "sample_range_by_rank: negative k or p");
+    const int64_t kk = std::min(k, std::min(m, l));
+    RC_REQUIRE(q.rows == m && q.cols == kk, RC_INVALID_ARGUMENT, "sample_range_by_rank: q must be %lld x %lld", (long long)m, (long long)kk);
+    if (kk == 0) return;
+    ArenaMark mark(c);
+    if (omega.p == nullptr) {
+        omega = tmp_rowmajor<T>(c, n, l);
+        fill_gaussian(c, omega, seed, 0);
+    } else {
+        RC_REQUIRE(omega.rows == n && omega.cols == l, RC_INVALID_ARGUMENT, "sample_range_by_rank: omega must be %lld x %lld", (long long)n, (long long)l);
+    }
+    Mat<T> w = tmp_colmajor<T>(c, m, l);
+    gemm<T>(c, 1, a, omega, 0, w);
+    int64_t *ind = c->alloc<int64_t>((size_t)l);
+    qrcp_core(c, w, kk, true, q, Mat<T>(), ind);
+}
+
+// full pivoted QR, Q only (helper of the power iteration)
+template <typename T>
+Mat<T> orth_full(rc_context *c, Mat<T> w) {
+    const int64_t k = std::min(w.rows, w.cols);
+    Mat<T> q = tmp_colmajor<T>(c, w.rows, k);
+    int64_t *ind = c->alloc<int64_t>((size_t)std::max<int64_t>(w.cols, 1));
+    qrcp_core(c, w, k, true, q, Mat<T>(), ind);
+    return q;
+}
+
+// SampleRangePowerIteration (/root/reference/src/random_sampling.rs:131-160).
+// The inner `let op_omega = ...` (:150) shadows the outer binding, so every
+// iteration restarts from A Omega and only the last one is kept: for any
+// it_count >= 1 the result is QRCP(A orth(A^H orth(A Omega)))[:, :k].
+template <typename T>
+void sample_range_power(rc_context *c, Mat<T> a, int64_t k, int64_t p, int64_t it_count, Mat<T> omega, uint64_t seed, Mat<T> q) {
+    if (it_count <= 0) { sample_range_by_rank(c, a, k, p, omega, seed, q); return; }
+    const int64_t m = a.rows, n = a.cols, l = k + p;
+    ArenaMark mark(c);
+    if (omega.p == nullptr) {
+        omega = tmp_rowmajor<T>(c, n, l);
+        fill_gaussian(c, omega, seed, 0);
+    } else {
+        RC_REQUIRE(omega.rows == n && omega.cols == l, RC_INVALID_ARGUMENT, "sample_range_power_iteration: omega must be %lld x %lld", (long long)n, (long long)l);
+    }
+    Mat<T> y0 = tmp_colmajor<T>(c, m, l);
+    gemm<T>(c, 1, a, omega, 0, y0);
+    Mat<T> q0 = orth_full(c, y0);                    // m x min(m, l)
+    Mat<T> z = tmp_colmajor<T>(c, n, q0.cols);
+    gemm<T>(c, 1, a.t(), q0, 0, z);                  // conj_matmat
+    Mat<T> wq = orth_full(c, z);                     // n x min(n, q0.cols)
+    Mat<T> y1 = tmp_colmajor<T>(c, m, wq.cols);
+    gemm<T>(c, 1, a, wq, 0, y1);
+    const int64_t kk = std::min(k, std::min(m, y1.cols));
+    RC_REQUIRE(q.rows == m && q.cols == kk, RC_INVALID_ARGUMENT, "sample_range_power_iteration: q must be %lld x %lld", (long long)m, (long long)kk);
+    int64_t *ind = c->alloc<int64_t>((size_t)std::max<int64_t>(y1.cols, 1));
+    qrcp_core(c, y1, kk, true, q, Mat<T>(), ind);
+}
+
+// MaxColNorm (/root/reference/src/random_sampling.rs:184-191) -> device scalar
+template <typename T>
+void max_col_norm_dev(rc_context *c, Mat<T> y, T *out_dev) {
+    ArenaMark mark(c);
+    T *ss = c->alloc<T>((size_t)std::max<int64_t>(y.cols, 1));
+    col_sumsq(c, y, ss);
+    max_sqrt(c, ss, y.cols, out_dev);
+}
+
+// AdaptiveSampling::sample_range_adaptive (/root/reference/src/random_sampling.rs:223-274)
+template <typename T>
+void sample_range_adaptive(rc_context *c, Mat<T> a, double rel_tol_d, int64_t s, Mat<T> omegas, uint64_t seed, Mat<T> qcap,
+                           int64_t *rank_out, int64_t *hist_rank, double *hist_res, int64_t hist_cap, int64_t *hist_len) {
+    const int64_t m = a.rows, n = a.cols, cap = qcap.cols;
+    RC_REQUIRE(s >= 1 && qcap.rows == m, RC_INVALID_ARGUMENT, "sample_range_adaptive: bad sample_size or q buffer");
+    const bool explicit_omega = omegas.p != nullptr;
+    if (explicit_omega) RC_REQUIRE(omegas.rows == n, RC_INVALID_ARGUMENT, "sample_range_adaptive: omegas must have %lld rows", (long long)n);
+    const T tol_factor = (T)(10.0 * std::sqrt(2.0 / 3.14159265358979323846));  // random_sampling.rs:231-234
+    const T rel_tol = (T)rel_tol_d;
+    const int64_t sq = std::min(m, s);  // columns a pivoted QR of an m x s block yields
+
+    int64_t blocks_used = 0;
+    auto next_omega = [&](Mat<T> dst) {
+        if (explicit_omega) {
+            RC_REQUIRE((blocks_used + 1) * s <= omegas.cols, RC_COMPRESSION_ERROR,
+                       "sample_range_adaptive: explicit Omega blocks exhausted after %lld blocks", (long long)blocks_used);
+            copy_mat(c, omegas.sub(0, n, blocks_used * s, s), dst);
+        } else {
+            fill_gaussian(c, dst, seed, (uint64_t)blocks_used * (uint64_t)(n * s));
+        }
+        ++blocks_used;
+    };
+
+    Mat<T> omega = tmp_rowmajor<T>(c, n, s);
+    Mat<T> y = tmp_colmajor<T>(c, m, s);
+    Mat<T> qacc = tmp_colmajor<T>(c, m, cap);
+    Mat<T> bacc = tmp_rowmajor<T>(c, cap, n);
+    Mat<T> t1 = tmp_colmajor<T>(c, cap, s);
+    int64_t *ind = c->alloc<int64_t>((size_t)s);
+    T *scal = c->alloc<T>(1);
+
+    next_omega(omega);
+    gemm<T>(c, 1, a, omega, 0, y);
+    T mc;
+    max_col_norm_dev(c, y, scal);
+    read_back(c, scal, &mc, 1);
+    const T operator_norm = mc * tol_factor;
+    T max_norm = operator_norm;
+    int64_t r = 0, nh = 0;
+    while (max_norm / operator_norm >= rel_tol) {
+        RC_REQUIRE(r + sq <= cap, RC_COMPRESSION_ERROR, "sample_range_adaptive: basis capacity %lld exhausted at rank %lld", (long long)cap, (long long)r);
+        if (r > 0) {  // y -= q (q^H y)
+            Mat<T> qr_ = qacc.sub(0, m, 0, r), tt = t1.sub(0, r, 0, s);
+            gemm<T>(c, 1, qr_.t(), y, 0, tt);
+            gemm<T>(c, -1, qr_, tt, 1, y);
+        }
+        Mat<T> qnew = qacc.sub(0, m, r, sq);
+        qrcp_core(c, y, sq, true, qnew, Mat<T>(), ind);       // pivoted QR of the block (:254)
+        gemm<T>(c, 1, qnew.t(), a, 0, bacc.sub(r, sq, 0, n));  // b = [b ; (A^H Q_new)^H] (:256-260)
+        r += sq;
+        next_omega(omega);
+        {   // y = A Omega - q (b Omega)  (:265-266)
+            Mat<T> qr_ = qacc.sub(0, m, 0, r), tt = t1.sub(0, r, 0, s);
+            gemm<T>(c, 1, bacc.sub(0, r, 0, n), omega, 0, tt);
+            gemm<T>(c, 1, a, omega, 0, y);
+            gemm<T>(c, -1, qr_, tt, 1, y);
+        }
+        max_col_norm_dev(c, y, scal);
+        read_back(c, scal, &mc, 1);
+        max_norm = mc * tol_factor;
+        if (nh < hist_cap) {
+            if (hist_rank) hist_rank[nh] = r;
+            if (hist_res) hist_res[nh] = (double)(max_norm / operator_norm);
+        }
+        ++nh;
+    }
+    copy_mat(c, qacc.sub(0, m, 0, r), qcap.sub(0, m, 0, r));
+    if (rank_out) *rank_out = r;
+    if (hist_len) *hist_len = std::min(nh, hist_cap);
+    RC_HIP(hipStreamSynchronize(c->stream));
+}
+
+// cfg3 "rSVD + ID" without host synchronisation
+template <typename T>
+void rsvd_id(rc_context *c, Mat<T> a, int64_t k, int64_t p, Mat<T> omega, uint64_t seed, const rc_rsvd_id_out &o) {
+    const int64_t m = a.rows, n = a.cols;
+    RC_REQUIRE(k >= 1 && k + p <= m && k <= n, RC_INVALID_ARGUMENT, "rsvd_id: need 1 <= k, k + p <= m, k <= n");
+    ArenaMark mark(c);
+    Mat<T> range = from_c<T>(o.range_q);
+    if (range.p == nullptr) range = tmp_colmajor<T>(c, m, k);
+    RC_REQUIRE(range.rows == m && range.cols == k, RC_INVALID_ARGUMENT, "rsvd_id: range_q must be m x k");
+    sample_range_by_rank(c, a, k, p, omega, seed, range);
+    // B = Q^H A once, shared by the SVD and the QR consumers
+    Mat<T> b = tmp_rowmajor<T>(c, k, n);
+    project(c, range, a, b);
+    const bool want_id = o.id_c.data || o.id_z.data || o.qr_q.data || o.qr_r.data || o.qr_ind;
+    Mat<T> wq;
+    if (want_id) {
+        wq = tmp_colmajor<T>(c, k, n);
+        copy_mat(c, b, wq);
+    }
+    if (o.u.data || o.s || o.vt.data) {
+        RC_REQUIRE(o.u.data && o.s && o.vt.data, RC_INVALID_ARGUMENT, "rsvd_id: u, s, vt must be given together");
+        Mat<T> ub = tmp_colmajor<T>(c, k, k);
+        svd_core(c, b.t(), true, ub, static_cast<T *>(o.s), from_c<T>(o.vt));  // destroys b
+        gemm<T>(c, 1, range, ub, 0, from_c<T>(o.u));
+    }
+    if (want_id) {
+        Mat<T> qb = tmp_colmajor<T>(c, k, k);
+        Mat<T> r = o.qr_r.data ? from_c<T>(o.qr_r) : tmp_rowmajor<T>(c, k, n);
+        int64_t *ind = o.qr_ind ? o.qr_ind : c->alloc<int64_t>((size_t)n);
+        qrcp_core(c, wq, k, true, qb, r, ind);
+        Mat<T> q = o.qr_q.data ? from_c<T>(o.qr_q) : tmp_colmajor<T>(c, m, k);
+        gemm<T>(c, 1, range, qb, 0, q);
+        if (o.id_c.data || o.id_z.data) {
+            RC_REQUIRE(o.id_c.data && o.id_z.data, RC_INVALID_ARGUMENT, "rsvd_id: id_c and id_z must be given together");
+            qr_column_id(c, q, r, ind, from_c<T>(o.id_c), from_c<T>(o.id_z));
+        }
+    }
+}
+
+// cfg5 unit: rank-k column ID of a dense matrix through the truncated factorization
+template <typename T>
+void column_id_rank(rc_context *c, Mat<T> a, int64_t k, Mat<T> cm, Mat<T> z, int64_t *col_ind) {
+    const int64_t m = a.rows, n = a.cols;
+    k = std::min(k, std::min(m, n));
+    ArenaMark mark(c);
+    Mat<T> w = tmp_colmajor<T>(c, m, n);
+    copy_mat(c, a, w);
+    Mat<T> q = tmp_colmajor<T>(c, m, k);
+    Mat<T> r = tmp_rowmajor<T>(c, k, n);
+    qrcp_core(c, w, k, true, q, r, col_ind);
+    qr_column_id(c, q, r, col_ind, cm, z);
+}
+
+template <typename T>
+void rank_by_tolerance(rc_context *c, Mat<T> tri, double tol, int64_t *rank) {
+    RC_REQUIRE(tol < 1.0 && 0.0 <= tol, RC_INVALID_ARGUMENT, "Require 0 <= tol < 1.0");
+    const int64_t len = std::min(tri.rows, tri.cols);
+    RC_REQUIRE(len >= 1, RC_COMPRESSION_ERROR, "rank_by_tolerance: empty factor");
+    ArenaMark mark(c);
+    T *d = c->alloc<T>((size_t)len);
+    copy_mat(c, Mat<T>(tri.p, len, 1, tri.rs + tri.cs, 1), Mat<T>(d, len, 1, 1, 1));
+    std::vector<T> h((size_t)len);
+    read_back(c, d, h.data(), (size_t)len);
+    for (int64_t i = 0; i < len; ++i) {
+        if ((double)std::fabs(h[i] / h[0]) < tol) { *rank = i; return; }  // qr.rs:194
+    }
+    fail(RC_COMPRESSION_ERROR, "Could not compress to desired tolerance");
+}
+
+template <typename T>
+void svd_rank_by_tolerance(rc_context *c, const T *s, int64_t len, double tol, int64_t *rank) {
+    RC_REQUIRE(tol < 1.0 && 0.0 <= tol, RC_INVALID_ARGUMENT, "Require 0 <= tol < 1.0");
+    RC_REQUIRE(len >= 1, RC_COMPRESSION_ERROR, "svd_rank_by_tolerance: empty spectrum");
+    std::vector<T> h((size_t)len);
+    read_back(c, s, h.data(), (size_t)len);
+    for (int64_t i = 0; i < len; ++i) {
+        if ((double)(h[i] / h[0]) < tol) { *rank = i; return; }  // svd.rs:95
+    }
+    fail(RC_COMPRESSION_ERROR, "Could not compress to desired tolerance");
+}
+
+template <typename T>
+void apply_perm_matrix(rc_context *c, int mode, Mat<T> in, const int64_t *perm, int64_t plen, Mat<T> out) {
+    RC_REQUIRE(in.rows == out.rows && in.cols == out.cols, RC_INVALID_ARGUMENT, "apply_permutation: shape mismatch");
+    ArenaMark mark(c);
+    const bool cols = (mode == RC_PERM_COL || mode == RC_PERM_COLINV);
+    const bool inv = (mode == RC_PERM_COLINV || mode == RC_PERM_ROWINV);
+    RC_REQUIRE(mode >= 0 && mode <= 3, RC_INVALID_ARGUMENT, "apply_permutation: unknown mode %d", mode);
+    if (cols) RC_REQUIRE(plen == in.cols, RC_INVALID_ARGUMENT, "Length of index array and number of columns differ.");
+    else RC_REQUIRE(plen == in.rows, RC_INVALID_ARGUMENT, "Length of index array and number of rows differ.");
+    const int64_t *idx = perm;
+    if (inv) {
+        int64_t *iv = c->alloc<int64_t>((size_t)std::max<int64_t>(plen, 1));
+        invert_perm(c, perm, plen, iv);
+        idx = iv;
+    }
+    if (cols) gather_cols(c, in, idx, out);
+    else gather_cols(c, in.t(), idx, out.t());
+}
+
+}  // namespace
+
+// ===========================================================================
+// extern "C"
+// ===========================================================================
+extern "C" {
+
+int32_t rc_abi_version(void) { return RC_ABI_VERSION; }
+
+rc_status rc_create(rc_context **ctx, int32_t device, void *hip_stream) {
+    if (!ctx) return RC_INVALID_ARGUMENT;
+    *ctx = nullptr;
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || device < 0 || device >= count) return RC_RUNTIME_ERROR;
+    rc_context *c = new rc_context();
+    c->device = device;
+    c->stream = static_cast<hipStream_t>(hip_stream);
+    *ctx = c;
+    return RC_OK;
+}
+
+rc_status rc_destroy(rc_context *ctx) {
+    if (!ctx) return RC_OK;
+    {
+        DeviceGuard dg(ctx->device);
+        ctx->release_all();
+    }
+    delete ctx;
+    return RC_OK;
+}
+
+rc_status rc_set_stream(rc_context *ctx, void *hip_stream) {
+    if (!ctx) return RC_INVALID_ARGUMENT;
+    DeviceGuard dg(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);  // the arena may still be in use on the old stream
+    ctx->stream = static_cast<hipStream_t>(hip_stream);
+    return RC_OK;
+}
+
+rc_status rc_synchronize(rc_context *ctx) {
+    if (!ctx) return RC_INVALID_ARGUMENT;
+    DeviceGuard dg(ctx->device);
+    hipError_t e = hipStreamSynchronize(ctx->stream);
+    if (e != hipSuccess) { ctx->last_error = hipGetErrorString(e); return RC_RUNTIME_ERROR; }
+    return RC_OK;
+}
+
+rc_status rc_reserve_workspace(rc_context *ctx, size_t bytes) {
+    if (!ctx) return RC_INVALID_ARGUMENT;
+    DeviceGuard dg(ctx->device);
+    try { ctx->reserve(bytes); } catch (const Error &e) { ctx->last_error = e.msg; return e.code; }
+    return RC_OK;
+}
+
+const char *rc_last_error_message(const rc_context *ctx) { return ctx ? ctx->last_error.c_str() : "null context"; }
+
+rc_status rc_device_malloc(rc_context *ctx, size_t bytes, void **ptr) {
+    if (!ctx || !ptr) return RC_INVALID_ARGUMENT;
+    DeviceGuard dg(ctx->device);
+    hipError_t e = hipMalloc(ptr, bytes ? bytes : 1);
+    if (e != hipSuccess) { ctx->last_error = hipGetErrorString(e); return RC_RUNTIME_ERROR; }
+    return RC_OK;
+}
+rc_status rc_device_free(rc_context *ctx, void *ptr) {
+    if (!ctx) return RC_INVALID_ARGUMENT;
+    DeviceGuard dg(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    hipError_t e = hipFree(ptr);
+    if (e != hipSuccess) { ctx->last_error = hipGetErrorString(e); return RC_RUNTIME_ERROR; }
+    return RC_OK;
+}
+rc_status rc_memcpy_h2d(rc_context *ctx, void *dst_dev, const void *src_host, size_t bytes) {
+    if (!ctx) return RC_INVALID_ARGUMENT;
+    DeviceGuard dg(ctx->device);
+    hipError_t e = hipMemcpyAsync(dst_dev, src_host, bytes, hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);  // pageable host memory: keep it simple and safe
+    if (e != hipSuccess) { ctx->last_error = hipGetErrorString(e); return RC_RUNTIME_ERROR; }
+    return RC_OK;
+}
+rc_status rc_memcpy_d2h(rc_context *ctx, void *dst_host, const void *src_dev, size_t bytes) {
+    if (!ctx) return RC_INVALID_ARGUMENT;
+    DeviceGuard dg(ctx->device);
+    hipError_t e = hipMemcpyAsync(dst_host, src_dev, bytes, hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (e != hipSuccess) { ctx->last_error = hipGetErrorString(e); return RC_RUNTIME_ERROR; }
+    return RC_OK;
+}
+
+rc_status rc_invert_permutation(rc_context *ctx, const int64_t *perm, int64_t n, int64_t *inverse) {
+    return guarded(ctx, [&] { invert_perm(ctx, perm, n, inverse); });
+}
+
+#define RC_DEFINE_TYPED(SUF, T)                                                                                                          \
+    rc_status rc_random_gaussian_##SUF(rc_context *ctx, rc_matrix out, uint64_t seed, uint64_t offset) {                                 \
+        return guarded(ctx, [&] { check_view(out, "out"); fill_gaussian<T>(ctx, from_c<T>(out), seed, offset); });                      \
+    }                                                                                                                                    \
+    rc_status rc_matmat_##SUF(rc_context *ctx, rc_matrix a, rc_matrix x, rc_matrix y) {                                                  \
+        return guarded(ctx, [&] { gemm<T>(ctx, 1, from_c<T>(a), from_c<T>(x), 0, from_c<T>(y)); });                                     \
+    }                                                                                                                                    \
+    rc_status rc_conj_matmat_##SUF(rc_context *ctx, rc_matrix a, rc_matrix x, rc_matrix y) {                                             \
+        return guarded(ctx, [&] { gemm<T>(ctx, 1, from_c<T>(a).t(), from_c<T>(x), 0, from_c<T>(y)); });                                 \
+    }                                                                                                                                    \
+    rc_status rc_gemm_##SUF(rc_context *ctx, int32_t ta, int32_t tb, T alpha, rc_matrix a, rc_matrix b, T beta, rc_matrix c) {           \
+        return guarded(ctx, [&] {                                                                                                        \
+            Mat<T> A = from_c<T>(a), B = from_c<T>(b);                                                                                   \
+            gemm<T>(ctx, alpha, ta ? A.t() : A, tb ? B.t() : B, beta, from_c<T>(c));                                                     \
+        });                                                                                                                              \
+    }                                                                                                                                    \
+    rc_status rc_rel_diff_fro_##SUF(rc_context *ctx, rc_matrix first, rc_matrix second, T *out) {                                        \
+        return guarded(ctx, [&] {                                                                                                        \
+            T *d = ctx->alloc<T>(2);                                                                                                     \
+            fro_diff<T>(ctx, from_c<T>(first), from_c<T>(second), d);                                                                    \
+            T h[2];                                                                                                                      \
+            read_back(ctx, d, h, 2);                                                                                                     \
+            *out = std::sqrt(h[0]) / std::sqrt(h[1]);                                                                                    \
+        });                                                                                                                              \
+    }                                                                                                                                    \
+    rc_status rc_apply_permutation_matrix_##SUF(rc_context *ctx, int32_t mode, rc_matrix in, const int64_t *perm, int64_t plen,          \
+                                                rc_matrix out) {                                                                         \
+        return guarded(ctx, [&] { apply_perm_matrix<T>(ctx, mode, from_c<T>(in), perm, plen, from_c<T>(out)); });                        \
+    }                                                                                                                                    \
+    rc_status rc_apply_permutation_vector_##SUF(rc_context *ctx, int32_t mode, rc_matrix in, const int64_t *perm, int64_t plen,          \
+                                                rc_matrix out) {                                                                         \
+        return guarded(ctx, [&] {                                                                                                        \
+            RC_REQUIRE(mode == RC_VPERM_INV || mode == RC_VPERM_NOINV, RC_INVALID_ARGUMENT, "unknown vector permutation mode");          \
+            RC_REQUIRE(in.cols == 1 && out.cols == 1 && plen == in.rows, RC_INVALID_ARGUMENT,                                           \
+                       "The input vector and the index array must have the same length");                                               \
+            apply_perm_matrix<T>(ctx, mode == RC_VPERM_INV ? RC_PERM_ROWINV : RC_PERM_ROW, from_c<T>(in), perm, plen, from_c<T>(out));   \
+        });                                                                                                                              \
+    }                                                                                                                                    \
+    rc_status rc_pivoted_qr_##SUF(rc_context *ctx, rc_matrix a, rc_matrix q, rc_matrix r, int64_t *ind) {                                \
+        return guarded(ctx, [&] { pivoted_qr<T>(ctx, from_c<T>(a), from_c<T>(q), from_c<T>(r), ind); });                                 \
+    }                                                                                                                                    \
+    rc_status rc_pivoted_lq_##SUF(rc_context *ctx, rc_matrix a, rc_matrix l, rc_matrix q, int64_t *ind) {                                \
+        return guarded(ctx, [&] { pivoted_qr<T>(ctx, from_c<T>(a).t(), from_c<T>(q).t(), from_c<T>(l).t(), ind); });                     \
+    }                                                                                                                                    \
+    rc_status rc_compute_svd_##SUF(rc_context *ctx, rc_matrix a, rc_matrix u, T *s, rc_matrix vt) {                                      \
+        return guarded(ctx, [&] { compute_svd<T>(ctx, from_c<T>(a), from_c<T>(u), s, from_c<T>(vt)); });                                 \
+    }                                                                                                                                    \
+    rc_status rc_rank_by_tolerance_##SUF(rc_context *ctx, rc_matrix tri, double tol, int64_t *rank) {                                    \
+        return guarded(ctx, [&] { rank_by_tolerance<T>(ctx, from_c<T>(tri), tol, rank); });                                              \
+    }                                                                                                                                    \
+    rc_status rc_qr_to_mat_##SUF(rc_context *ctx, rc_matrix q, rc_matrix r, const int64_t *ind, rc_matrix out) {                         \
+        return guarded(ctx, [&] {                                                                                                        \
+            Mat<T> R = from_c<T>(r);                                                                                                     \
+            int64_t *inv = ctx->alloc<int64_t>((size_t)std::max<int64_t>(R.cols, 1));                                                   \
+            invert_perm(ctx, ind, R.cols, inv);                                                                                          \
+            Mat<T> rp = tmp_rowmajor<T>(ctx, R.rows, R.cols);                                                                            \
+            gather_cols<T>(ctx, R, inv, rp);                                                                                             \
+            gemm<T>(ctx, 1, from_c<T>(q), rp, 0, from_c<T>(out));                                                                        \
+        });                                                                                                                              \
+    }                                                                                                                                    \
+    rc_status rc_lq_to_mat_##SUF(rc_context *ctx, rc_matrix l, rc_matrix q, const int64_t *ind, rc_matrix out) {                         \
+        return guarded(ctx, [&] {                                                                                                        \
+            Mat<T> L = from_c<T>(l);                                                                                                     \
+            int64_t *inv = ctx->alloc<int64_t>((size_t)std::max<int64_t>(L.rows, 1));                                                   \
+            invert_perm(ctx, ind, L.rows, inv);                                                                                          \
+            Mat<T> lp = tmp_rowmajor<T>(ctx, L.rows, L.cols);                                                                            \
+            gather_cols<T>(ctx, L.t(), inv, lp.t());                                                                                     \
+            gemm<T>(ctx, 1, lp, from_c<T>(q), 0, from_c<T>(out));                                                                        \
+        });                                                                                                                              \
+    }                                                                                                                                    \
+    rc_status rc_qr_column_id_##SUF(rc_context *ctx, rc_matrix q, rc_matrix r, const int64_t *ind, rc_matrix c, rc_matrix z) {           \
+        return guarded(ctx, [&] { qr_column_id<T>(ctx, from_c<T>(q), from_c<T>(r), ind, from_c<T>(c), from_c<T>(z)); });                 \
+    }                                                                                                                                    \
+    rc_status rc_lq_row_id_##SUF(rc_context *ctx, rc_matrix l, rc_matrix q, const int64_t *ind, rc_matrix x, rc_matrix rr) {             \
+        return guarded(ctx, [&] { lq_row_id<T>(ctx, from_c<T>(l), from_c<T>(q), ind, from_c<T>(x), from_c<T>(rr)); });                   \
+    }                                                                                                                                    \
+    rc_status rc_qr_from_range_estimate_##SUF(rc_context *ctx, rc_matrix range, rc_matrix a, rc_matrix q, rc_matrix r, int64_t *ind) {   \
+        return guarded(ctx, [&] { qr_from_range<T>(ctx, from_c<T>(range), from_c<T>(a), from_c<T>(q), from_c<T>(r), ind); });            \
+    }                                                                                                                                    \
+    rc_status rc_svd_rank_by_tolerance_##SUF(rc_context *ctx, const T *s, int64_t len, double tol, int64_t *rank) {                      \
+        return guarded(ctx, [&] { svd_rank_by_tolerance<T>(ctx, s, len, tol, rank); });                                                  \
+    }                                                                                                                                    \
+    rc_status rc_svd_to_mat_##SUF(rc_context *ctx, rc_matrix u, const T *s, rc_matrix vt, rc_matrix out) {                               \
+        return guarded(ctx, [&] {                                                                                                        \
+            Mat<T> VT = from_c<T>(vt);                                                                                                   \
+            Mat<T> sv = tmp_rowmajor<T>(ctx, VT.rows, VT.cols);                                                                          \
+            scale_rows<T>(ctx, s, VT, sv);                                                                                               \
+            gemm<T>(ctx, 1, from_c<T>(u), sv, 0, from_c<T>(out));                                                                        \
+        });                                                                                                                              \
+    }                                                                                                                                    \
+    rc_status rc_svd_to_qr_##SUF(rc_context *ctx, rc_matrix u, const T *s, rc_matrix vt, rc_matrix q, rc_matrix r, int64_t *ind) {       \
+        return guarded(ctx, [&] {                                                                                                        \
+            Mat<T> VT = from_c<T>(vt), Q = from_c<T>(q);                                                                                 \
+            Mat<T> w = tmp_colmajor<T>(ctx, VT.rows, VT.cols);                                                                           \
+            scale_rows<T>(ctx, s, VT, w);                                                                                                \
+            const int64_t k = Q.cols;                                                                                                    \
+            RC_REQUIRE(k <= std::min(VT.rows, VT.cols), RC_INVALID_ARGUMENT, "svd_to_qr: rank exceeds min(r, n)");                       \
+            Mat<T> qb = tmp_colmajor<T>(ctx, VT.rows, k);                                                                                \
+            qrcp_core<T>(ctx, w, k, true, qb, from_c<T>(r), ind);                                                                        \
+            gemm<T>(ctx, 1, from_c<T>(u), qb, 0, Q);                                                                                     \
+        });                                                                                                                              \
+    }                                                                                                                                    \
+    rc_status rc_svd_from_range_estimate_##SUF(rc_context *ctx, rc_matrix range, rc_matrix a, rc_matrix u, T *s, rc_matrix vt) {         \
+        return guarded(ctx, [&] { svd_from_range<T>(ctx, from_c<T>(range), from_c<T>(a), from_c<T>(u), s, from_c<T>(vt)); });            \
+    }                                                                                                                                    \
+    rc_status rc_column_id_two_sided_##SUF(rc_context *ctx, rc_matrix c, rc_matrix c_out, rc_matrix x, int64_t *row_ind) {               \
+        return guarded(ctx, [&] {                                                                                                        \
+            Mat<T> C = from_c<T>(c);                                                                                                     \
+            const int64_t m = C.rows, k = C.cols, kk = std::min(m, k);                                                                   \
+            Mat<T> l = tmp_rowmajor<T>(ctx, m, kk), ql = tmp_rowmajor<T>(ctx, kk, k);                                                    \
+            pivoted_qr<T>(ctx, C.t(), ql.t(), l.t(), row_ind); /* LQ::compute_from, qr.rs:354-362 */                                     \
+            lq_row_id<T>(ctx, l, ql, row_ind, from_c<T>(c_out), from_c<T>(x));                                                           \
+        });                                                                                                                              \
+    }                                                                                                                                    \
+    rc_status rc_row_id_two_sided_##SUF(rc_context *ctx, rc_matrix r, rc_matrix x, rc_matrix r_out, int64_t *col_ind) {                  \
+        return guarded(ctx, [&] {                                                                                                        \
+            Mat<T> R = from_c<T>(r);                                                                                                     \
+            const int64_t k = R.rows, n = R.cols, kk = std::min(k, n);                                                                   \
+            Mat<T> q = tmp_colmajor<T>(ctx, k, kk), rr = tmp_rowmajor<T>(ctx, kk, n);                                                    \
+            pivoted_qr<T>(ctx, R, q, rr, col_ind);                                                                                       \
+            qr_column_id<T>(ctx, q, rr, col_ind, from_c<T>(x), from_c<T>(r_out));                                                        \
+        });                                                                                                                              \
+    }                                                                                                                                    \
+    rc_status rc_max_col_norm_##SUF(rc_context *ctx, rc_matrix y, T *out) {                                                              \
+        return guarded(ctx, [&] {                                                                                                        \
+            T *d = ctx->alloc<T>(1);                                                                                                     \
+            max_col_norm_dev<T>(ctx, from_c<T>(y), d);                                                                                   \
+            read_back(ctx, d, out, 1);                                                                                                   \
+        });                                                                                                                              \
+    }                                                                                                                                    \
+    rc_status rc_sample_range_by_rank_##SUF(rc_context *ctx, rc_matrix a, int64_t k, int64_t p, rc_matrix omega, uint64_t seed,          \
+                                            rc_matrix q) {                                                                               \
+        return guarded(ctx, [&] { sample_range_by_rank<T>(ctx, from_c<T>(a), k, p, from_c<T>(omega), seed, from_c<T>(q)); });            \
+    }                                                                                                                                    \
+    rc_status rc_sample_range_power_iteration_##SUF(rc_context *ctx, rc_matrix a, int64_t k, int64_t p, int64_t it, rc_matrix omega,     \
+                                                    uint64_t seed, rc_matrix q) {                                                        \
+        return guarded(ctx, [&] { sample_range_power<T>(ctx, from_c<T>(a), k, p, it, from_c<T>(omega), seed, from_c<T>(q)); });          \
+    }                                                                                                                                    \
+    rc_status rc_sample_range_adaptive_##SUF(rc_context *ctx, rc_matrix a, double rel_tol, int64_t s, rc_matrix omegas, uint64_t seed,   \
+                                             rc_matrix q_cap, int64_t *rank, int64_t *hist_rank, double *hist_res, int64_t hist_cap,     \
+                                             int64_t *hist_len) {                                                                        \
+        return guarded(ctx, [&] {                                                                                                        \
+            sample_range_adaptive<T>(ctx, from_c<T>(a), rel_tol, s, from_c<T>(omegas), seed, from_c<T>(q_cap), rank, hist_rank,          \
+                                     hist_res, hist_cap, hist_len);                                                                      \
+        });                                                                                                                              \
+    }                                                                                                                                    \
+    rc_status rc_rsvd_id_##SUF(rc_context *ctx, rc_matrix a, int64_t k, int64_t p, rc_matrix omega, uint64_t seed,                       \
+                               const rc_rsvd_id_out *out) {                                                                              \
+        return guarded(ctx, [&] {                                                                                                        \
+            RC_REQUIRE(out != nullptr, RC_INVALID_ARGUMENT, "rsvd_id: null output descriptor");                                          \
+            rsvd_id<T>(ctx, from_c<T>(a), k, p, from_c<T>(omega), seed, *out);                                                           \
+        });                                                                                                                              \
+    }                                                                                                                                    \
+    rc_status rc_column_id_rank_##SUF(rc_context *ctx, rc_matrix a, int64_t k, rc_matrix c, rc_matrix z, int64_t *col_ind) {             \
+        return guarded(ctx, [&] { column_id_rank<T>(ctx, from_c<T>(a), k, from_c<T>(c), from_c<T>(z), col_ind); });                      \
+    }
+
+RC_DEFINE_TYPED(f64, double)
+RC_DEFINE_TYPED(f32, float)
+
+}  // extern "C"

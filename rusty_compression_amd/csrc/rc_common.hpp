@@ -1,0 +1,151 @@
+// Internal shared declarations of librusty_compression_amd (gfx950 only).
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/rusty_compression_amd.h"
+
+namespace rc {
+
+// ---------------------------------------------------------------------------
+// strided device view (mirror of rc_matrix with a typed pointer)
+// ---------------------------------------------------------------------------
+template <typename T>
+struct Mat {
+    T *p = nullptr;
+    int64_t rows = 0, cols = 0, rs = 0, cs = 0;
+
+    __host__ __device__ Mat() {}
+    __host__ __device__ Mat(T *p_, int64_t r, int64_t c, int64_t rs_, int64_t cs_) : p(p_), rows(r), cols(c), rs(rs_), cs(cs_) {}
+    __host__ __device__ inline T &at(int64_t i, int64_t j) const { return p[i * rs + j * cs]; }
+    // sub-view [r0, r0+nr) x [c0, c0+nc)
+    __host__ __device__ Mat<T> sub(int64_t r0, int64_t nr, int64_t c0, int64_t nc) const {
+        return Mat<T>(p + r0 * rs + c0 * cs, nr, nc, rs, cs);
+    }
+    __host__ __device__ Mat<T> t() const { return Mat<T>(p, cols, rows, cs, rs); }
+    __host__ __device__ bool empty() const { return rows == 0 || cols == 0; }
+};
+
+template <typename T>
+inline Mat<T> from_c(const rc_matrix &m) {
+    return Mat<T>(static_cast<T *>(m.data), m.rows, m.cols, m.row_stride, m.col_stride);
+}
+// freshly allocated column-major / row-major views
+template <typename T>
+inline Mat<T> colmajor(T *p, int64_t rows, int64_t cols, int64_t ld) { return Mat<T>(p, rows, cols, 1, ld); }
+template <typename T>
+inline Mat<T> rowmajor(T *p, int64_t rows, int64_t cols, int64_t ld) { return Mat<T>(p, rows, cols, ld, 1); }
+
+// ---------------------------------------------------------------------------
+// error handling
+// ---------------------------------------------------------------------------
+struct Error {
+    rc_status code;
+    std::string msg;
+};
+
+[[noreturn]] inline void fail(rc_status code, const char *fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    throw Error{code, std::string(buf)};
+}
+
+#define RC_HIP(expr)                                                                                   \
+    do {                                                                                               \
+        hipError_t _e = (expr);                                                                        \
+        if (_e != hipSuccess) ::rc::fail(RC_RUNTIME_ERROR, "%s failed: %s (%s:%d)", #expr,             \
+                                         hipGetErrorString(_e), __FILE__, __LINE__);                   \
+    } while (0)
+
+#define RC_REQUIRE(cond, code, ...)                  \
+    do {                                             \
+        if (!(cond)) ::rc::fail(code, __VA_ARGS__);  \
+    } while (0)
+
+}  // namespace rc
+
+// ---------------------------------------------------------------------------
+// context: device, stream, workspace arena
+// ---------------------------------------------------------------------------
+struct rc_context {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    std::string last_error;
+
+    // Workspace arena.  Every C-ABI call resets the bump pointer on entry; all
+    // work is ordered on `stream`, so a later call may reuse the bytes of an
+    // earlier one.  Growth (rare: first calls only) synchronises the stream.
+    char *arena = nullptr;
+    size_t arena_size = 0;
+    size_t arena_off = 0;
+    size_t arena_high = 0;              // high-water mark of the current call
+    std::vector<void *> overflow;       // extra blocks taken while the arena was too small
+    void *pinned = nullptr;             // small pinned host buffer for scalar read-backs
+    size_t pinned_size = 0;
+
+    void reset_arena();
+    void *alloc_bytes(size_t bytes);
+    template <typename T>
+    T *alloc(size_t n) { return static_cast<T *>(alloc_bytes(n * sizeof(T))); }
+    void reserve(size_t bytes);
+    void release_all();
+};
+
+namespace rc {
+
+// marks/restores the arena inside a call (stack discipline for temporaries)
+struct ArenaMark {
+    rc_context *c;
+    size_t off;
+    explicit ArenaMark(rc_context *ctx) : c(ctx), off(ctx->arena_off) {}
+    ~ArenaMark() { c->arena_off = off; }
+};
+
+// ---------------------------------------------------------------------------
+// kernel launchers (defined in the kernels_*.hip translation units)
+// ---------------------------------------------------------------------------
+template <typename T> void fill_gaussian(rc_context *c, Mat<T> out, uint64_t seed, uint64_t offset);
+template <typename T> void copy_mat(rc_context *c, Mat<T> src, Mat<T> dst);                 // dst = src (any strides)
+template <typename T> void fill_identity(rc_context *c, Mat<T> dst);                        // dst = [I | 0] / [I ; 0]
+template <typename T> void fill_zero(rc_context *c, Mat<T> dst);
+template <typename T> void scale_rows(rc_context *c, const T *s, Mat<T> src, Mat<T> dst);   // dst[i,:] = s[i] * src[i,:]
+template <typename T> void gather_cols(rc_context *c, Mat<T> src, const int64_t *idx, Mat<T> dst);  // dst[:, j] = src[:, idx[j]]
+void invert_perm(rc_context *c, const int64_t *perm, int64_t n, int64_t *inv);
+void iota_i64(rc_context *c, int64_t *p, int64_t n);
+// column 2-norms squared; out[j] = sum_i a(i,j)^2
+template <typename T> void col_sumsq(rc_context *c, Mat<T> a, T *out);
+// device scalar reductions; results land in device memory `out`
+template <typename T> void max_sqrt(rc_context *c, const T *v, int64_t n, T *out);           // out = sqrt(max v)
+template <typename T> void fro_diff(rc_context *c, Mat<T> a, Mat<T> b, T *out2);             // out2[0]=|a-b|_F^2, out2[1]=|b|_F^2
+template <typename T> void adaptive_residual_update(rc_context *c, Mat<T> y, Mat<T> corr);   // y -= corr
+
+// C = alpha * A * B + beta * C on views (transposes are expressed through strides)
+template <typename T> void gemm(rc_context *c, T alpha, Mat<T> a, Mat<T> b, T beta, Mat<T> cmat);
+
+// Householder QR with optional column pivoting (LAPACK ?geqp3 / ?laqp2 semantics).
+//   w      : m x n COLUMN-MAJOR working matrix (cs = ld, rs = 1), overwritten
+//   jpvt   : n (position -> original column of w).  Columns are NOT moved physically.
+//   tau    : kmax
+//   vn     : 2n scratch (partial norms)
+template <typename T> void geqp3_inplace(rc_context *c, Mat<T> w, int64_t kmax, bool pivot, int64_t *jpvt, T *tau, T *vn);
+// r(i, p) = (i <= p) ? w(i, jpvt[p]) : 0  for i < r.rows
+template <typename T> void extract_r(rc_context *c, Mat<T> w, const int64_t *jpvt, Mat<T> r);
+// qw (m x kq column-major) = H_0 ... H_{k-1} [I ; 0], reflector j stored in column jpvt[j] of w
+template <typename T> void form_q(rc_context *c, Mat<T> w, const int64_t *jpvt, const T *tau, int64_t k, Mat<T> qw);
+// solve T X = B in place; t: k x k upper triangular view (any strides), b: k x nrhs view
+template <typename T> void trsm_upper(rc_context *c, Mat<T> t, Mat<T> b);
+// one-sided Jacobi SVD of the square column-major n x n matrix g (destroyed):
+//   uc (n x n col-major) = left vectors, s (n) descending, vc (n x n col-major) = right vectors
+template <typename T> void jacobi_svd(rc_context *c, Mat<T> g, Mat<T> vwork, Mat<T> uc, T *s, Mat<T> vc);
+
+}  // namespace rc

@@ -1,0 +1,59 @@
+"""Shared helpers of the parity tests."""
+import os
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def golden(name):
+    return np.load(os.path.join(GOLDEN, name), allow_pickle=False)
+
+
+def rel(a, b):
+    a = np.asarray(a, dtype=np.float64)
+    b = np.asarray(b, dtype=np.float64)
+    return float(np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-300))
+
+
+def npy(t):
+    return t.detach().cpu().numpy() if hasattr(t, "detach") else np.asarray(t)
+
+
+def sign_normalise(u, vt):
+    """Largest-|.| entry of each left singular vector positive (per-pair sign ambiguity of an SVD)."""
+    u = np.array(u, copy=True)
+    vt = np.array(vt, copy=True)
+    for j in range(u.shape[1]):
+        i = int(np.argmax(np.abs(u[:, j])))
+        if u[i, j] < 0:
+            u[:, j] *= -1
+            vt[j, :] *= -1
+    return u, vt
+
+
+def is_permutation(ind, n):
+    return sorted(np.asarray(ind).tolist()) == list(range(n))
+
+
+# tolerances (stated once, used everywhere)
+#   f64: factors <= 1e-10 relative Frobenius (BASELINE.json north_star), singular values <= 1e-12 relative
+#   f32: the reference's own f32 thresholds (1e-4 factors, 1e-5 singular values / round trips)
+TOL = {
+    np.dtype(np.float64): dict(factor=1e-10, sval=1e-12, orth=1e-12, recon=1e-12),
+    np.dtype(np.float32): dict(factor=1e-4, sval=1e-5, orth=1e-5, recon=1e-5),
+}
+
+
+def stable_prefix(r, dtype):
+    """Number of leading pivots that are determined by the data rather than by rounding.
+
+    Column-pivoted QR picks the largest remaining partial norm; once |r_jj| has
+    dropped to the rounding level of the working precision the remaining columns
+    are numerical noise and their order legitimately depends on summation order
+    (SURVEY.md F8).  Pivot indices are compared bit-exactly on this prefix only."""
+    d = np.abs(np.diag(np.asarray(r, dtype=np.float64)))
+    floor = {np.dtype(np.float64): 1e-12, np.dtype(np.float32): 2e-5}[np.dtype(dtype)] * d[0]
+    below = np.nonzero(d < floor)[0]
+    return int(below[0]) if below.size else int(d.size)
