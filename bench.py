@@ -1,0 +1,267 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of the MI355X-native compression engine.
+
+Workload (BASELINE.json configs[2], the one `metric` is quoted on; it fits one GPU):
+  8192 x 8192 f64 dense i.i.d. N(0,1), rank k = 128, oversampling p = 5:
+  one STEP = one "rSVD + ID" compression through the C ABI (rc_rsvd_id_f64):
+      sample_range_by_rank -> SVD::compute_from_range_estimate
+                           -> QR::compute_from_range_estimate -> column_id
+  with A resident in HBM and Omega generated on the device.
+
+  python bench.py --gpus N --steps K --warmup W      (N > 1: launched by torch.distributed.run)
+
+Independent matrices are the unit of parallelism: every rank
+compresses its own matrices (weak scaling, no data-path collective); within a rank
+`--streams S` independent compressions are in flight on S HIP streams, each replayed
+from a hipGraph, so the launch-bound pivot chain of one overlaps the GEMMs of another.
+Rank 0 prints ONE JSON line.
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+F64_MFMA_PEAK_TFLOPS = 78.6   # MI355X f64 matrix peak (vendor datasheet value)
+HBM_PEAK_GBS = 8000.0         # /opt/skills/guides/MI355X_MICROARCH.md: 8 TB/s spec (6.3 TB/s achievable)
+
+
+def work_model(m, n, k, p, with_id=True):
+    """Algorithmic flops / bytes of one compression (DESIGN.md 'Work model')."""
+    l = k + p
+    fl = {
+        "sketch_gemm": 2.0 * m * n * l,
+        "qrcp_y": 2.0 * m * l * l - (2.0 / 3.0) * l ** 3,
+        "form_q": 2.0 * m * l * l - (2.0 / 3.0) * l ** 3,
+        "project_gemm": 2.0 * m * n * k,
+        "svd_b": 6.0 * n * k * k + 22.0 * k ** 3,
+        "u_gemm": 2.0 * m * k * k,
+    }
+    by = 2 * 8.0 * m * n + 8.0 * (m * k + k + k * n)
+    if with_id:
+        fl["qrcp_b"] = 2.0 * n * k * k - (2.0 / 3.0) * k ** 3
+        fl["trsm"] = 1.0 * k * k * (n - k)
+        fl["c_gemm"] = 2.0 * m * k * k
+        by += 8.0 * (m * k + k * n) + 8.0 * n
+    return fl, by
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=40)
+    ap.add_argument("--warmup", type=int, default=4)
+    ap.add_argument("--streams", type=int, default=4, help="independent compressions in flight per GPU")
+    ap.add_argument("--size", type=int, default=8192)
+    ap.add_argument("--rank", type=int, default=128)
+    ap.add_argument("--oversample", type=int, default=5)
+    ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying hipGraphs")
+    ap.add_argument("--no-id", action="store_true", help="rSVD only (skip QR-from-range + column ID)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-baseline-reps", type=int, default=1)
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+
+    import rusty_compression_amd as rc
+    from rusty_compression_amd import _lib
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the engine has no CPU path")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist  # noqa: F811
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+
+    m = n = args.size
+    k, p = args.rank, args.oversample
+    l = k + p
+    S = max(1, args.streams)
+    with_id = not args.no_id
+    dt = torch.float64
+
+    # ---- per-stream state: own matrix, own outputs, own context ------------------------
+    lanes = []
+    for s in range(S):
+        st = torch.cuda.Stream()
+        with torch.cuda.stream(st):
+            ctx = _lib.default_context()
+            a = rc.random_gaussian((m, n), rc.Rng(1000 * rank + s + 1), dt)  # resident in HBM
+            mk = lambda r, c: torch.empty((r, c), dtype=dt, device="cuda")  # noqa: E731
+            bufs = dict(range_q=mk(m, k), u=mk(m, k), s=torch.empty(k, dtype=dt, device="cuda"), vt=mk(k, n))
+            if with_id:
+                bufs.update(qr_q=mk(m, k), qr_r=mk(k, n), qr_ind=torch.empty(n, dtype=torch.int64, device="cuda"), id_c=mk(m, k), id_z=mk(k, n))
+            none = _lib.mat(None)
+            out = _lib.rc_rsvd_id_out(
+                _lib.mat(bufs["range_q"]), _lib.mat(bufs["u"]), ctypes.c_void_p(bufs["s"].data_ptr()), _lib.mat(bufs["vt"]),
+                _lib.mat(bufs["qr_q"]) if with_id else none, _lib.mat(bufs["qr_r"]) if with_id else none,
+                ctypes.c_void_p(bufs["qr_ind"].data_ptr()) if with_id else ctypes.c_void_p(None),
+                _lib.mat(bufs["id_c"]) if with_id else none, _lib.mat(bufs["id_z"]) if with_id else none)
+
+            def call(ctx=ctx, a=a, out=out, seed=7 + s):
+                ctx.call("rc_rsvd_id_f64", _lib.mat(a), ctypes.c_int64(k), ctypes.c_int64(p), _lib.mat(None), ctypes.c_uint64(seed), ctypes.byref(out))
+
+            call()  # eager warm-up: sizes the workspace arena (required before capture)
+            ctx.synchronize()
+            graph = ctypes.c_void_p(None)
+            if not args.no_graph:
+                ctx.check(_lib.lib().rc_graph_begin_capture(ctx._h))
+                call()
+                ctx.check(_lib.lib().rc_graph_end_capture(ctx._h, ctypes.byref(graph)))
+            lanes.append(dict(stream=st, ctx=ctx, a=a, bufs=bufs, out=out, call=call, graph=graph))
+
+    def step(i):
+        ln = lanes[i % S]
+        if ln["graph"]:
+            ln["ctx"].check(_lib.lib().rc_graph_launch(ln["ctx"]._h, ln["graph"]))
+        else:
+            ln["call"]()
+
+    def sync_all():
+        for ln in lanes:
+            ln["ctx"].synchronize()
+        torch.cuda.synchronize()
+
+    # ---- sanity of what is being timed (lane 0) -----------------------------------------
+    sync_all()
+    q0 = lanes[0]["bufs"]["range_q"]
+    with torch.cuda.stream(lanes[0]["stream"]):
+        gram = rc.dot(q0.t(), q0)
+    sync_all()
+    orth = float((gram - torch.eye(k, dtype=dt, device="cuda")).abs().max())
+    s0 = lanes[0]["bufs"]["s"]
+    assert orth < 1e-10 and bool((s0[:-1] >= s0[1:]).all()) and float(s0[-1]) > 0, "bench sanity check failed"
+
+    # ---- warm-up, then K timed steps -----------------------------------------------------
+    for i in range(args.warmup):
+        step(i)
+    sync_all()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(i)
+    sync_all()
+    t1 = time.perf_counter()
+    if dist is not None:
+        dist.barrier()
+    elapsed = t1 - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # ---- stage / kernel timers: HIP events on lane 0's own stream, eager launches --------
+    prof = {}
+    ln = lanes[0]
+    lib = _lib.lib()
+    lib.rc_profile_enable(ln["ctx"]._h, 1)
+    lib.rc_profile_reset(ln["ctx"]._h)
+    nprof = 3
+    for _ in range(nprof):
+        ln["call"]()
+    cnt = ctypes.c_int32(0)
+    ln["ctx"].check(lib.rc_profile_count(ln["ctx"]._h, ctypes.byref(cnt)))
+    for i in range(cnt.value):
+        name = ctypes.create_string_buffer(192)
+        ms = ctypes.c_double(0)
+        calls = ctypes.c_int64(0)
+        lib.rc_profile_get(ln["ctx"]._h, i, name, 192, ctypes.byref(ms), ctypes.byref(calls))
+        prof[name.value.decode()] = (ms.value, calls.value)
+    lib.rc_profile_enable(ln["ctx"]._h, 0)
+
+    fl, by = work_model(m, n, k, p, with_id)
+    total_flops = sum(fl.values())
+    key = f"kernel:k_gemm_mfma<f64> M={m} N={l} K={n}"
+    roof = None
+    if key in prof and prof[key][1] > 0:
+        ms_launch = prof[key][0] / prof[key][1]
+        achieved = fl["sketch_gemm"] / (ms_launch * 1e-3) / 1e12
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+        if os.path.exists(tpath):
+            try:
+                traffic = json.load(open(tpath)).get("k_gemm_mfma_sketch_bytes_per_launch")
+            except Exception:
+                traffic = None
+        roof = {"bound": "mfma", "kernel": "k_gemm_mfma<double,...> (sketch Y = A*Omega, %dx%dx%d)" % (m, l, n), "achieved": round(achieved, 3),
+                "peak": F64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / F64_MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
+                "avg_launch_ms": round(ms_launch, 4), "launches_timed": prof[key][1],
+                "flops_per_launch": fl["sketch_gemm"], "hbm_gbs_algorithmic": round(8.0 * m * n / (ms_launch * 1e-3) / 1e9, 1),
+                "method": "HIP events on the launching stream around each launch (rc_profile_*), eager pass after the timed region"}
+
+    # ---- CPU baseline: the oracle in the reference's call shape on this box's host cores --
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        from oracle import ref_lapack as o
+
+        try:
+            from threadpoolctl import threadpool_info
+
+            cores = max([int(x.get("num_threads", 1)) for x in threadpool_info()] or [1])
+        except Exception:
+            cores = os.cpu_count() or 1
+        a_h = lanes[0]["a"].cpu().numpy()
+        om_h = np.random.default_rng(0).standard_normal((n, l))
+        tc0 = time.perf_counter()
+        for _ in range(args.cpu_baseline_reps):
+            o.rsvd_id_reference_shape(a_h, om_h, k, faithful=True)
+        tc = (time.perf_counter() - tc0) / args.cpu_baseline_reps
+        cpu = {"value": round(1.0 / tc, 4), "unit": "compressions/s", "cores": cores, "kind": "port",
+               "sample": "%d compression(s) of the same 8192x8192 f64 matrix, rSVD+ID, reference call shape "
+                         "(per-column gemv loops for A*Omega and A^H*Q, ?geqp3+?orgqr, ?gesdd, per-column ?trtrs) via oracle/ref_lapack.py "
+                         "(SciPy LAPACK/OpenBLAS), %.2f s each" % (args.cpu_baseline_reps, tc),
+               "seconds_per_compression": round(tc, 3)}
+
+    if rank == 0:
+        steps_total = args.steps * world
+        value = steps_total / elapsed
+        stage_ms = {kk: round(v[0] / max(v[1], 1), 4) for kk, v in sorted(prof.items()) if kk.startswith(("stage:", "op:"))}
+        line = {
+            "metric": "GB/s + compressions/sec, 8192x8192 f64 rank-128 rSVD+ID",
+            "value": round(value, 3),
+            "unit": "compressions/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 4),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f64",
+            "data": "synthetic",
+            "config": {"workload": "cfg3: %dx%d f64 dense N(0,1), rank-%d rSVD%s, p=%d (BASELINE.json configs[2])" % (m, n, k, "+ID" if with_id else "", p),
+                       "streams_per_gpu": S, "hipgraph": not args.no_graph, "parallelism": "independent matrices, %d per GPU in flight" % S},
+            "gb_per_s": round(value * by / 1e9, 2),
+            "tflops_algorithmic": round(value * total_flops / 1e12, 3),
+            "frac_of_f64_mfma_peak_whole_pipeline": round(value * total_flops / 1e12 / (F64_MFMA_PEAK_TFLOPS * world), 4),
+            "bytes_per_compression": by,
+            "flops_per_compression": total_flops,
+            "roofline": roof,
+            "cpu_baseline": cpu,
+            "stage_ms_single_stream_eager": stage_ms,
+        }
+        print(json.dumps(line), flush=True)
+
+    for ln in lanes:
+        if ln["graph"]:
+            _lib.lib().rc_graph_destroy(ln["ctx"]._h, ln["graph"])
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

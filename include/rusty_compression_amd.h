@@ -86,6 +86,25 @@ rc_status rc_device_free(rc_context *ctx, void *ptr);
 rc_status rc_memcpy_h2d(rc_context *ctx, void *dst_dev, const void *src_host, size_t bytes);
 rc_status rc_memcpy_d2h(rc_context *ctx, void *dst_host, const void *src_dev, size_t bytes); /* synchronous */
 
+/* hipGraph capture: everything issued on the context's stream between begin and
+ * end becomes one replayable graph (launch-bound chains such as the ~130
+ * dependent pivot steps of a pivoted QR replay without host launch overhead).
+ * Only calls without host synchronisation may be captured, and the context must
+ * have run the same call once eagerly before (workspace sizing).  No reference
+ * counterpart: the reference is synchronous host code. */
+rc_status rc_graph_begin_capture(rc_context *ctx);
+rc_status rc_graph_end_capture(rc_context *ctx, void **graph_exec);
+rc_status rc_graph_launch(rc_context *ctx, void *graph_exec);
+rc_status rc_graph_destroy(rc_context *ctx, void *graph_exec);
+
+/* Stage / kernel timers: HIP events recorded on the context's stream around the
+ * dominant kernels and pipeline stages (used by bench.py for the roofline line).
+ * rc_profile_count / rc_profile_get synchronise the stream. */
+rc_status rc_profile_enable(rc_context *ctx, int32_t on);
+rc_status rc_profile_reset(rc_context *ctx);
+rc_status rc_profile_count(rc_context *ctx, int32_t *n);
+rc_status rc_profile_get(rc_context *ctx, int32_t i, char *name, int32_t name_cap, double *total_ms, int64_t *calls);
+
 /* ------------------------------------------------------- random_matrix.rs -- */
 /* RandomMatrix::random_gaussian (src/random_matrix.rs:21, :120-125): i.i.d.
  * N(0,1), drawn in f64 and cast.  Element (i, j) is sample number i*cols + j

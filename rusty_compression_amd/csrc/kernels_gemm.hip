@@ -239,8 +239,12 @@ static void launch_cfg(rc_context *c, GemmArgs<T> g) {
         RC_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_set[c->device & 63] = true;
     }
-    hipLaunchKernelGGL(kern, dim3((unsigned)tiles, (unsigned)splits), dim3(WM * WN * 64), lds, c->stream, g);
+    {
+        ProfScope ps(c, "kernel:k_gemm_mfma<%s> M=%lld N=%lld K=%lld", sizeof(T) == 8 ? "f64" : "f32", (long long)g.M, (long long)g.N, (long long)g.K);
+        hipLaunchKernelGGL(kern, dim3((unsigned)tiles, (unsigned)splits), dim3(WM * WN * 64), lds, c->stream, g);
+    }
     if (splits > 1) {
+        ProfScope ps(c, "kernel:k_splitk_reduce M=%lld N=%lld splits=%d", (long long)g.M, (long long)g.N, splits);
         int grid = (int)std::min<int64_t>(cdiv(g.M * g.N, 256), 4096);
         hipLaunchKernelGGL(k_splitk_reduce<T>, dim3(grid), dim3(256), 0, c->stream, g);
     }

@@ -251,6 +251,7 @@ void geqp3_inplace(rc_context *c, Mat<T> w, int64_t kmax, bool pivot, int64_t *j
     const int64_t m = w.rows, n = w.cols;
     if (m == 0 || n == 0) return;
     kmax = std::min(kmax, std::min(m, n));
+    ProfScope ps(c, "op:geqp3 %lldx%lld k=%lld pivot=%d", (long long)m, (long long)n, (long long)kmax, pivot ? 1 : 0);
     T *vn1 = vn, *vn2 = vn + n;
     const int pv = pivot ? 1 : 0;
     hipLaunchKernelGGL(k_qr_init<T>, dim3((unsigned)std::min<int64_t>(n, 65535)), dim3(256), 0, c->stream, w, pv, jpvt, vn1, vn2);
@@ -367,6 +368,7 @@ void form_q(rc_context *c, Mat<T> w, const int64_t *jpvt, const T *tau, int64_t 
     const int64_t m = w.rows;
     const unsigned grid = (unsigned)qw.cols;
     if (k <= 0) { fill_identity(c, qw); return; }
+    ProfScope ps(c, "op:form_q %lldx%lld k=%lld", (long long)m, (long long)qw.cols, (long long)k);
     if (m <= 256 * 2) hipLaunchKernelGGL((k_form_q<T, 2>), dim3(grid), dim3(256), 0, c->stream, w, jpvt, tau, k, qw);
     else if (m <= 256 * 8) hipLaunchKernelGGL((k_form_q<T, 8>), dim3(grid), dim3(256), 0, c->stream, w, jpvt, tau, k, qw);
     else if (m <= 256 * 32) hipLaunchKernelGGL((k_form_q<T, 32>), dim3(grid), dim3(256), 0, c->stream, w, jpvt, tau, k, qw);
@@ -394,6 +396,7 @@ template <typename T>
 void trsm_upper(rc_context *c, Mat<T> t, Mat<T> b) {
     RC_REQUIRE(t.rows == t.cols && t.rows == b.rows, RC_INVALID_ARGUMENT, "trsm: shape mismatch");
     if (b.empty()) return;
+    ProfScope ps(c, "op:trsm_upper k=%lld nrhs=%lld", (long long)t.rows, (long long)b.cols);
     hipLaunchKernelGGL(k_trsm_upper<T>, dim3((unsigned)cdiv(b.cols, 256)), dim3(256), 0, c->stream, t, b);
 }
 

@@ -124,6 +124,7 @@ void jacobi_svd(rc_context *c, Mat<T> g, Mat<T> vwork, Mat<T> uc, T *s, Mat<T> v
     RC_REQUIRE(g.rows <= 1024, RC_INVALID_ARGUMENT, "compute_svd: min(m, n) = %lld > 1024 is not supported by the single-workgroup Jacobi core",
                (long long)g.rows);
     if (g.rows == 0) return;
+    ProfScope ps(c, "op:jacobi_svd n=%lld", (long long)g.rows);
     hipLaunchKernelGGL(k_jacobi_svd<T>, dim3(1), dim3(1024), 0, c->stream, g, vwork, uc, s, vc, 60);
 }
 

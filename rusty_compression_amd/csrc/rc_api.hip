@@ -38,7 +38,8 @@ void *rc_context::alloc_bytes(size_t bytes) {
     if (arena_off + bytes <= arena_size) {
         p = arena + arena_off;
     } else {
-        // not capturable in a hipGraph: warm the context up with one eager call first
+        RC_REQUIRE(!capturing, RC_RUNTIME_ERROR,
+                   "workspace arena too small during hipGraph capture: run the same call once eagerly first (or rc_reserve_workspace)");
         RC_HIP(hipMalloc(&p, bytes));
         overflow.push_back(p);
     }
@@ -57,8 +58,34 @@ void rc_context::reserve(size_t bytes) {
     arena_size = bytes;
 }
 
+hipEvent_t rc_context::prof_event() {
+    if (!prof_free.empty()) { hipEvent_t e = prof_free.back(); prof_free.pop_back(); return e; }
+    hipEvent_t e = nullptr;
+    (void)hipEventCreate(&e);
+    return e;
+}
+
+void rc_context::prof_resolve() {
+    if (prof_pending.empty()) return;
+    (void)hipStreamSynchronize(stream);
+    for (auto &p : prof_pending) {
+        float ms = 0;
+        if (hipEventElapsedTime(&ms, p.beg, p.end) == hipSuccess) {
+            auto &a = prof_acc[p.name];
+            a.ms += ms;
+            a.calls += 1;
+        }
+        prof_free.push_back(p.beg);
+        prof_free.push_back(p.end);
+    }
+    prof_pending.clear();
+}
+
 void rc_context::release_all() {
     (void)hipStreamSynchronize(stream);
+    prof_resolve();
+    for (hipEvent_t e : prof_free) (void)hipEventDestroy(e);
+    prof_free.clear();
     for (void *p : overflow) (void)hipFree(p);
     overflow.clear();
     if (arena) (void)hipFree(arena);
@@ -443,10 +470,16 @@ void rsvd_id(rc_context *c, Mat<T> a, int64_t k, int64_t p, Mat<T> omega, uint64
     Mat<T> range = from_c<T>(o.range_q);
     if (range.p == nullptr) range = tmp_colmajor<T>(c, m, k);
     RC_REQUIRE(range.rows == m && range.cols == k, RC_INVALID_ARGUMENT, "rsvd_id: range_q must be m x k");
-    sample_range_by_rank(c, a, k, p, omega, seed, range);
+    {
+        ProfScope ps(c, "stage:sample_range_by_rank");
+        sample_range_by_rank(c, a, k, p, omega, seed, range);
+    }
     // B = Q^H A once, shared by the SVD and the QR consumers
     Mat<T> b = tmp_rowmajor<T>(c, k, n);
-    project(c, range, a, b);
+    {
+        ProfScope ps(c, "stage:project B=Q^H A");
+        project(c, range, a, b);
+    }
     const bool want_id = o.id_c.data || o.id_z.data || o.qr_q.data || o.qr_r.data || o.qr_ind;
     Mat<T> wq;
     if (want_id) {
@@ -455,11 +488,13 @@ void rsvd_id(rc_context *c, Mat<T> a, int64_t k, int64_t p, Mat<T> omega, uint64
     }
     if (o.u.data || o.s || o.vt.data) {
         RC_REQUIRE(o.u.data && o.s && o.vt.data, RC_INVALID_ARGUMENT, "rsvd_id: u, s, vt must be given together");
+        ProfScope ps(c, "stage:svd of B + U=Q Ub");
         Mat<T> ub = tmp_colmajor<T>(c, k, k);
         svd_core(c, b.t(), true, ub, static_cast<T *>(o.s), from_c<T>(o.vt));  // destroys b
         gemm<T>(c, 1, range, ub, 0, from_c<T>(o.u));
     }
     if (want_id) {
+        ProfScope ps(c, "stage:qrcp of B + column_id");
         Mat<T> qb = tmp_colmajor<T>(c, k, k);
         Mat<T> r = o.qr_r.data ? from_c<T>(o.qr_r) : tmp_rowmajor<T>(c, k, n);
         int64_t *ind = o.qr_ind ? o.qr_ind : c->alloc<int64_t>((size_t)n);
@@ -619,6 +654,81 @@ rc_status rc_memcpy_d2h(rc_context *ctx, void *dst_host, const void *src_dev, si
     hipError_t e = hipMemcpyAsync(dst_host, src_dev, bytes, hipMemcpyDeviceToHost, ctx->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
     if (e != hipSuccess) { ctx->last_error = hipGetErrorString(e); return RC_RUNTIME_ERROR; }
+    return RC_OK;
+}
+
+// ---- hipGraph capture of the work issued on the context's stream -------------
+rc_status rc_graph_begin_capture(rc_context *ctx) {
+    if (!ctx) return RC_INVALID_ARGUMENT;
+    DeviceGuard dg(ctx->device);
+    if (ctx->capturing) { ctx->last_error = "capture already in progress"; return RC_INVALID_ARGUMENT; }
+    if (!ctx->overflow.empty()) ctx->reset_arena();  // settle the arena before anything is baked into a graph
+    hipError_t e = hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal);
+    if (e != hipSuccess) { ctx->last_error = hipGetErrorString(e); return RC_RUNTIME_ERROR; }
+    ctx->capturing = true;
+    return RC_OK;
+}
+rc_status rc_graph_end_capture(rc_context *ctx, void **graph_exec) {
+    if (!ctx || !graph_exec) return RC_INVALID_ARGUMENT;
+    DeviceGuard dg(ctx->device);
+    *graph_exec = nullptr;
+    hipGraph_t graph = nullptr;
+    hipError_t e = hipStreamEndCapture(ctx->stream, &graph);
+    ctx->capturing = false;
+    if (e != hipSuccess || !graph) { ctx->last_error = std::string("hipStreamEndCapture: ") + hipGetErrorString(e); return RC_RUNTIME_ERROR; }
+    hipGraphExec_t exec = nullptr;
+    e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+    (void)hipGraphDestroy(graph);
+    if (e != hipSuccess) { ctx->last_error = std::string("hipGraphInstantiate: ") + hipGetErrorString(e); return RC_RUNTIME_ERROR; }
+    *graph_exec = exec;
+    return RC_OK;
+}
+rc_status rc_graph_launch(rc_context *ctx, void *graph_exec) {
+    if (!ctx || !graph_exec) return RC_INVALID_ARGUMENT;
+    DeviceGuard dg(ctx->device);
+    hipError_t e = hipGraphLaunch(static_cast<hipGraphExec_t>(graph_exec), ctx->stream);
+    if (e != hipSuccess) { ctx->last_error = hipGetErrorString(e); return RC_RUNTIME_ERROR; }
+    return RC_OK;
+}
+rc_status rc_graph_destroy(rc_context *ctx, void *graph_exec) {
+    if (!ctx) return RC_INVALID_ARGUMENT;
+    if (!graph_exec) return RC_OK;
+    DeviceGuard dg(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    (void)hipGraphExecDestroy(static_cast<hipGraphExec_t>(graph_exec));
+    return RC_OK;
+}
+
+// ---- stage / kernel timers ----------------------------------------------------
+rc_status rc_profile_enable(rc_context *ctx, int32_t on) {
+    if (!ctx) return RC_INVALID_ARGUMENT;
+    ctx->prof_on = on != 0;
+    return RC_OK;
+}
+rc_status rc_profile_reset(rc_context *ctx) {
+    if (!ctx) return RC_INVALID_ARGUMENT;
+    DeviceGuard dg(ctx->device);
+    ctx->prof_resolve();
+    ctx->prof_acc.clear();
+    return RC_OK;
+}
+rc_status rc_profile_count(rc_context *ctx, int32_t *n) {
+    if (!ctx || !n) return RC_INVALID_ARGUMENT;
+    DeviceGuard dg(ctx->device);
+    ctx->prof_resolve();
+    *n = (int32_t)ctx->prof_acc.size();
+    return RC_OK;
+}
+rc_status rc_profile_get(rc_context *ctx, int32_t i, char *name, int32_t name_cap, double *total_ms, int64_t *calls) {
+    if (!ctx || i < 0 || i >= (int32_t)ctx->prof_acc.size()) return RC_INVALID_ARGUMENT;
+    auto it = ctx->prof_acc.begin();
+    std::advance(it, i);
+    if (name && name_cap > 0) {
+        std::strncpy(name, it->first.c_str(), (size_t)name_cap - 1);
+        name[name_cap - 1] = 0;
+    }
+    if (total_ms) *total_ms = it->second.ms;
+    if (calls) *calls = it->second.calls;
     return RC_OK;
 }
 

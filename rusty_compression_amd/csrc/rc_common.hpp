@@ -7,6 +7,7 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
+#include <map>
 #include <string>
 #include <vector>
 
@@ -93,6 +94,17 @@ struct rc_context {
     void *pinned = nullptr;             // small pinned host buffer for scalar read-backs
     size_t pinned_size = 0;
 
+    // hipGraph capture state and the event-based stage/kernel timers (rc_profile_*)
+    bool capturing = false;
+    bool prof_on = false;
+    struct ProfPending { std::string name; hipEvent_t beg, end; };
+    struct ProfAcc { double ms = 0; int64_t calls = 0; };
+    std::vector<ProfPending> prof_pending;
+    std::vector<hipEvent_t> prof_free;
+    std::map<std::string, ProfAcc> prof_acc;
+    hipEvent_t prof_event();
+    void prof_resolve();
+
     void reset_arena();
     void *alloc_bytes(size_t bytes);
     template <typename T>
@@ -102,6 +114,32 @@ struct rc_context {
 };
 
 namespace rc {
+
+// Times everything issued on the context's stream during its lifetime with a pair
+// of HIP events recorded ON THAT STREAM (no-op unless rc_profile_enable(ctx, 1),
+// and never while a hipGraph is being captured).
+struct ProfScope {
+    rc_context *c;
+    hipEvent_t beg = nullptr;
+    std::string name;
+    ProfScope(rc_context *ctx, const char *fmt, ...) : c(ctx) {
+        if (!c->prof_on || c->capturing) return;
+        char buf[160];
+        va_list ap;
+        va_start(ap, fmt);
+        vsnprintf(buf, sizeof(buf), fmt, ap);
+        va_end(ap);
+        name = buf;
+        beg = c->prof_event();
+        (void)hipEventRecord(beg, c->stream);
+    }
+    ~ProfScope() {
+        if (!beg) return;
+        hipEvent_t end = c->prof_event();
+        (void)hipEventRecord(end, c->stream);
+        c->prof_pending.push_back({name, beg, end});
+    }
+};
 
 // marks/restores the arena inside a call (stack discipline for temporaries)
 struct ArenaMark {

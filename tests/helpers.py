@@ -57,3 +57,27 @@ def stable_prefix(r, dtype):
     floor = {np.dtype(np.float64): 1e-12, np.dtype(np.float32): 2e-5}[np.dtype(dtype)] * d[0]
     below = np.nonzero(d < floor)[0]
     return int(below[0]) if below.size else int(d.size)
+
+
+def agreed_pivot_prefix(ind, r, ind_ref, r_ref, dtype):
+    """Length of the leading run on which two pivoted QRs took the same pivots, with the
+    near-tie rule of SURVEY.md section 7 applied at the first disagreement.
+
+    LAPACK only keeps the down-dated partial norms accurate to ~sqrt(eps) (the tol3z
+    recompute rule), so when two candidate columns' partial norms agree to that level the
+    choice depends on summation order.  A disagreement at position j is accepted only if
+    (1) j lies beyond nothing else (all earlier pivots identical) and (2) both
+    factorizations report the same |r_jj| to the tie tolerance, i.e. each picked a column
+    whose partial norm was maximal to within rounding.  f64 callers additionally assert
+    that no disagreement happens inside the stable prefix at all."""
+    ns = stable_prefix(r_ref, dtype)
+    ind = np.asarray(ind)[:ns]
+    ind_ref = np.asarray(ind_ref)[:ns]
+    diff = np.nonzero(ind != ind_ref)[0]
+    if diff.size == 0:
+        return ns
+    j = int(diff[0])
+    tie = {np.dtype(np.float64): 1e-6, np.dtype(np.float32): 5e-3}[np.dtype(dtype)]
+    a, b = abs(float(r[j, j])), abs(float(r_ref[j, j]))
+    assert abs(a - b) <= tie * max(a, b), f"pivot {j} differs and is not a near tie: |r_jj| {a} vs {b}"
+    return j

@@ -1,0 +1,409 @@
+"""GPU parity tests (run with -m gpu on an MI355X): every call goes through the
+C ABI (librusty_compression_amd.so) and is compared with
+
+  * the committed golden vectors (tests/golden/, SciPy-LAPACK oracle),
+  * the oracle run live on the same seeded inputs,
+  * the reference's own property tests, restated (file:line cited per test).
+
+Tolerances (tests/helpers.py TOL): f64 factors <= 1e-10 relative Frobenius,
+singular values <= 1e-12 relative; f32 1e-4 / 1e-5.  Permutation indices are
+compared bit-exactly on the prefix that is determined by the data (helpers.stable_prefix).
+"""
+import numpy as np
+import pytest
+import torch
+
+import rusty_compression_amd as rc
+from oracle import ref_lapack as o
+from tests.helpers import TOL, agreed_pivot_prefix, golden, is_permutation, npy, rel, sign_normalise, stable_prefix
+
+pytestmark = pytest.mark.gpu
+
+QRCP_FILES = [f"qrcp_{t}_{s}_{g}.npz" for t in ("f64", "f32") for s in ("thin", "thick") for g in ("s5", "s10")]
+CT = rc.CompressionType
+
+
+def test_native_library_is_the_one_loaded():
+    from rusty_compression_amd import _lib
+
+    assert torch.cuda.is_available()
+    assert _lib.lib().rc_abi_version() == 1
+    with open("/proc/self/maps") as f:
+        assert "librusty_compression_amd.so" in f.read()
+
+
+# ---------------------------------------------------------------- GEMM (a2, a3, N9)
+@pytest.mark.parametrize("dtype,tol", [(np.float64, 1e-13), (np.float32, 2e-6)])
+def test_gemm_all_layouts_and_ragged_shapes(dtype, tol):
+    rng = np.random.default_rng(0)
+    for (m, k, n) in ((100, 50, 37), (256, 512, 133), (128, 1000, 300), (33, 7, 5), (300, 260, 69), (1, 64, 1), (513, 129, 257), (5, 1, 9), (160, 2100, 128)):
+        a = rng.standard_normal((m, k)).astype(dtype)
+        b = rng.standard_normal((k, n)).astype(dtype)
+        ref = a.astype(np.float64) @ b.astype(np.float64)
+        for la in ("C", "F"):
+            for lb in ("C", "F"):
+                ta = torch.from_numpy(a).cuda() if la == "C" else torch.from_numpy(np.ascontiguousarray(a.T)).cuda().t()
+                tb = torch.from_numpy(b).cuda() if lb == "C" else torch.from_numpy(np.ascontiguousarray(b.T)).cuda().t()
+                assert rel(npy(rc.dot(ta, tb)), ref) <= tol, (m, k, n, la, lb)
+    # strided sub-views (neither operand starts at an aligned address, odd leading dimension)
+    big = rng.standard_normal((70, 91)).astype(dtype)
+    tb = torch.from_numpy(big).cuda()
+    assert rel(npy(rc.dot(tb[3:45, 5:60], tb[1:56, 7:40])), big[3:45, 5:60].astype(np.float64) @ big[1:56, 7:40].astype(np.float64)) <= tol
+    # matrix . vector (Apply on Ix1, col_interp_decomp.rs:134-143)
+    v = rng.standard_normal(91).astype(dtype)
+    assert rel(npy(rc.dot(tb, v)), big.astype(np.float64) @ v.astype(np.float64)) <= tol
+    # matmat / conj_matmat (types.rs:58-101)
+    x = rng.standard_normal((91, 12)).astype(dtype)
+    y = rng.standard_normal((70, 12)).astype(dtype)
+    assert rel(npy(rc.matmat(big, x)), big.astype(np.float64) @ x) <= tol
+    assert rel(npy(rc.conj_matmat(big, y)), big.T.astype(np.float64) @ y) <= tol
+
+
+def test_gemm_is_deterministic_under_split_k():
+    a = rc.random_gaussian((512, 8192), rc.Rng(1))
+    b = rc.random_gaussian((8192, 69), rc.Rng(2))
+    c1 = rc.dot(a, b)
+    c2 = rc.dot(a, b)
+    assert torch.equal(c1, c2)
+    assert rel(npy(c1), npy(a) @ npy(b)) <= 1e-13
+
+
+# ---------------------------------------------------------------- permutation (a17)
+def test_permutation_known_answers_of_the_reference():
+    g = golden("perm_known.npz")  # values of src/permutation.rs:192-239
+    for mode in ("COL", "COLINV", "ROW", "ROWINV"):
+        assert np.array_equal(npy(rc.apply_permutation(g["mat"], g["perm"], rc.MatrixPermutationMode[mode])), g[mode])
+        assert np.array_equal(npy(rc.apply_permutation(g["mat"].astype(np.float32), g["perm"], rc.MatrixPermutationMode[mode])), g[mode])
+    assert np.array_equal(npy(rc.apply_permutation(g["vec"], g["perm"], rc.VectorPermutationMode.NOINV)), g["NOINV"])
+    assert np.array_equal(npy(rc.apply_permutation(g["vec"], g["perm"], rc.VectorPermutationMode.INV)), g["INV"])
+    assert npy(rc.invert_permutation_vector(g["perm"])).tolist() == [1, 2, 0]
+
+
+def test_permutation_random_and_length_asserts():
+    rng = np.random.default_rng(3)
+    a = rng.standard_normal((37, 53))
+    pc, pr = rng.permutation(53), rng.permutation(37)
+    for mode, p in (("COL", pc), ("COLINV", pc), ("ROW", pr), ("ROWINV", pr)):
+        assert np.array_equal(npy(rc.apply_permutation(a, p, rc.MatrixPermutationMode[mode])), o.apply_permutation_matrix(a, p, mode))
+    with pytest.raises(AssertionError):  # src/permutation.rs:96-99
+        rc.apply_permutation(a, pr, rc.MatrixPermutationMode.COL)
+    with pytest.raises(AssertionError):
+        rc.apply_permutation(a[:, 0].copy(), pc, rc.VectorPermutationMode.INV)
+
+
+# ---------------------------------------------------------------- Gaussian fill (a1)
+def test_gaussian_stream_is_counter_based_and_normal():
+    g = npy(rc.random_gaussian((4096, 133), rc.Rng(7)))
+    assert abs(g.mean()) < 5e-3 and abs(g.std() - 1.0) < 5e-3
+    assert abs(np.mean(g ** 3)) < 2e-2 and abs(np.mean(g ** 4) - 3.0) < 5e-2
+    r1 = rc.Rng(7)
+    a, b = npy(rc.random_gaussian((10, 7), r1)), npy(rc.random_gaussian((5, 7), r1))
+    assert np.array_equal(np.vstack([a, b]), npy(rc.random_gaussian((15, 7), rc.Rng(7))))  # consumption order = row-major
+    assert not np.array_equal(a, npy(rc.random_gaussian((10, 7), rc.Rng(8))))
+    g32 = npy(rc.random_gaussian((10, 7), rc.Rng(7), torch.float32))
+    assert np.array_equal(g32, a.astype(np.float32))  # drawn in f64 then cast (random_matrix.rs:123)
+
+
+# ---------------------------------------------------------------- pivoted QR / LQ (a5, a6)
+@pytest.mark.parametrize("name", QRCP_FILES)
+def test_pivoted_qr_and_lq_match_golden(name):
+    g = golden(name)
+    a = g["a"]
+    tol = TOL[a.dtype]
+    q, r, ind = (npy(t) for t in rc.pivoted_qr(a))
+    ns = agreed_pivot_prefix(ind, r, g["ind"], g["r"], a.dtype)
+    assert is_permutation(ind, a.shape[1]) and ns >= 15
+    if a.dtype == np.float64:
+        assert ns == stable_prefix(g["r"], a.dtype)  # f64: bit-exact permutation on everything the data determines
+    assert rel(r[:ns, :ns], g["r"][:ns, :ns]) <= tol["factor"]
+    assert rel(o.apply_permutation_matrix(r[:ns], ind, "COLINV"), o.apply_permutation_matrix(g["r"][:ns], g["ind"], "COLINV")) <= tol["factor"]
+    if name.endswith("s5.npz") and ns == stable_prefix(g["r"], a.dtype):  # cond ~1e5: Q is determined to ~cond * eps
+        assert rel(q, g["q"]) <= (1e-9 if a.dtype == np.float64 else 5e-2)
+    # the reference's own assertions (src/pivoted_qr.rs:225-242): orthogonality and column match, 1e-6
+    assert np.abs(q.T @ q - np.eye(q.shape[1])).max() < 1e-6
+    prod = q @ r
+    for j in range(a.shape[1]):
+        assert np.linalg.norm(prod[:, j] - a[:, ind[j]]) < 1e-6 * max(np.linalg.norm(a[:, ind[j]]), 1e-30) or np.linalg.norm(a[:, ind[j]]) < 1e-5
+    l, ql, indl = (npy(t) for t in rc.pivoted_lq(a))
+    nsl = agreed_pivot_prefix(indl, l, g["indl"], g["l"], a.dtype)
+    assert is_permutation(indl, a.shape[0]) and nsl >= 15
+    if a.dtype == np.float64:
+        assert nsl == stable_prefix(g["l"], a.dtype)
+    assert rel(l[:nsl, :nsl], g["l"][:nsl, :nsl]) <= tol["factor"]
+    assert np.abs(ql @ ql.T - np.eye(ql.shape[0])).max() < 1e-6  # src/pivoted_qr.rs:273-281
+    prod = l @ ql
+    for i in range(a.shape[0]):
+        assert np.linalg.norm(prod[i] - a[indl[i]]) < 1e-6 * max(np.linalg.norm(a[indl[i]]), 1e-30) or np.linalg.norm(a[indl[i]]) < 1e-5
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+@pytest.mark.parametrize("shape", [(512, 69), (64, 512), (300, 300), (2100, 40), (17, 1), (1, 17), (9000, 6)])
+def test_pivoted_qr_shapes_against_live_oracle(dtype, shape):
+    rng = np.random.default_rng(shape[0] * 7 + shape[1])
+    a = o.random_approximate_low_rank_matrix(shape, 1.0, 1e-5, rng, dtype) if min(shape) > 1 else rng.standard_normal(shape).astype(dtype)
+    tol = TOL[a.dtype]
+    q, r, ind = o.pivoted_qr(a)
+    gq, gr, gi = (npy(t) for t in rc.pivoted_qr(a))
+    ns = agreed_pivot_prefix(gi, gr, ind, r, dtype)
+    assert is_permutation(gi, shape[1])
+    if dtype == np.float64:
+        assert ns == stable_prefix(r, dtype)
+    assert rel(gr[:ns, :ns], r[:ns, :ns]) <= tol["factor"]
+    assert rel(gq @ gr, a[:, gi]) <= (1e-13 if dtype == np.float64 else 5e-6)
+    assert np.abs(gq.T @ gq - np.eye(gq.shape[1])).max() <= (1e-13 if dtype == np.float64 else 1e-5)
+
+
+def test_pivoted_qr_accepts_any_layout_and_leaves_input_untouched():
+    rng = np.random.default_rng(9)
+    a = o.random_approximate_low_rank_matrix((120, 80), 1.0, 1e-5, rng)
+    ref = o.pivoted_qr(a)
+    t_c = torch.from_numpy(a).cuda()
+    t_f = torch.from_numpy(np.ascontiguousarray(a.T)).cuda().t()
+    big = torch.zeros((130, 95), dtype=torch.float64, device="cuda")
+    big[5:125, 10:90] = t_c
+    for t in (t_c, t_f, big[5:125, 10:90]):
+        before = t.clone()
+        q, r, ind = rc.pivoted_qr(t)
+        assert torch.equal(t, before)
+        assert np.array_equal(npy(ind), ref[2]) and rel(npy(r), ref[1]) <= 1e-10
+
+
+def test_truncated_pivoted_qr_equals_the_leading_part_of_the_full_one():
+    rng = np.random.default_rng(12)
+    for dtype in (np.float64, np.float32):
+        a = o.random_approximate_low_rank_matrix((200, 120), 1.0, 1e-5, rng, dtype)
+        q, r, ind = o.pivoted_qr(a)
+        gq, gr, gi = (npy(t) for t in rc.pivoted_qr(a, rank=30))
+        tol = TOL[a.dtype]
+        assert np.array_equal(gi[:30], ind[:30]) and is_permutation(gi, 120)
+        assert rel(gq, q[:, :30]) <= (1e-9 if dtype == np.float64 else 5e-2)
+        assert rel(o.apply_permutation_matrix(gr, gi, "COLINV"), o.apply_permutation_matrix(r[:30], ind, "COLINV")) <= tol["factor"]
+
+
+def test_pivot_ties_take_the_first_maximum_like_idamax():
+    # duplicate and zero columns: exact ties in the partial norms
+    rng = np.random.default_rng(4)
+    base = rng.standard_normal((40, 6))
+    a = np.concatenate([base, base, np.zeros((40, 3)), base[:, :2]], axis=1)
+    q, r, ind = o.pivoted_qr(a)
+    gq, gr, gi = (npy(t) for t in rc.pivoted_qr(a))
+    assert np.array_equal(gi[:6], ind[:6])
+    assert rel(gq @ gr, a[:, gi]) <= 1e-13
+    z = np.zeros((8, 5))
+    gq, gr, gi = (npy(t) for t in rc.pivoted_qr(z))
+    assert gi.tolist() == [0, 1, 2, 3, 4] and np.all(gr == 0) and np.array_equal(gq, np.eye(8, 5))
+
+
+# ---------------------------------------------------------------- SVD (a11, a12)
+@pytest.mark.parametrize("name", QRCP_FILES)
+def test_compute_svd_matches_golden(name):
+    g = golden(name)
+    a = g["a"]
+    tol = TOL[a.dtype]
+    u, s, vt = (npy(t) for t in rc.compute_svd(a))
+    assert np.abs(s - g["s"]).max() / g["s"][0] <= tol["sval"]
+    assert np.all(np.diff(s) <= 0)
+    assert rel(u @ np.diag(s) @ vt, a) <= tol["recon"]
+    assert np.abs(u.T @ u - np.eye(len(s))).max() <= (1e-12 if a.dtype == np.float64 else 1e-4)
+    assert np.abs(vt @ vt.T - np.eye(len(s))).max() <= (1e-12 if a.dtype == np.float64 else 1e-4)
+    # singular vectors of well separated, well conditioned singular values, after fixing the pair signs
+    un, vtn = sign_normalise(u, vt)
+    lead = 10
+    assert rel(un[:, :lead], g["u"][:, :lead]) <= (1e-9 if a.dtype == np.float64 else 1e-3)
+    assert rel(vtn[:lead], g["vt"][:lead]) <= (1e-9 if a.dtype == np.float64 else 1e-3)
+
+
+@pytest.mark.parametrize("dtype,shape,tol", [(np.float64, (100, 50), 1e-12), (np.float32, (100, 50), 1e-5), (np.float64, (50, 100), 1e-12), (np.float32, (50, 100), 1e-5)])
+def test_svd_reference_properties(dtype, shape, tol):
+    """src/svd.rs:214-223 (SVD -> QR -> matrix), :246-253 (RANK(20)), :277-281 (ADAPTIVE)."""
+    rng = np.random.default_rng(21)
+    a = o.random_approximate_low_rank_matrix(shape, 1.0, 1e-10, rng, dtype)
+    svd = rc.SVD.compute_from(a)
+    assert rc.rel_diff_fro(svd.to_qr().to_mat(), a) < tol
+    c = svd.compress(CT.RANK(20))
+    assert c.u.shape[1] == 20 and c.vt.shape[0] == 20
+    assert rc.rel_diff_fro(c.to_mat(), a) < 1e-4
+    ad = svd.compress(CT.ADAPTIVE(1e-4))
+    assert rc.rel_diff_fro(ad.to_mat(), a) < 1e-4
+    assert ad.rank() == o.SVD.compute_from(a).compress("ADAPTIVE", 1e-4).rank()
+
+
+# ---------------------------------------------------------------- compress / to_mat / IDs (a7-a10, a13-a16)
+@pytest.mark.parametrize("dtype,shape", [(np.float64, (100, 50)), (np.float32, (100, 50)), (np.float64, (50, 100)), (np.float32, (50, 100))])
+def test_qr_compression_and_ids_reference_properties(dtype, shape):
+    """src/qr.rs:432-450, :466-483, :497-524, :538-564; src/col_interp_decomp.rs:180-223; src/row_interp_decomp.rs:180-217."""
+    rng = np.random.default_rng(33)
+    a = o.random_approximate_low_rank_matrix(shape, 1.0, 1e-10, rng, dtype)
+    tol = 1e-4
+    qr = rc.QR.compute_from(a)
+    c = qr.compress(CT.RANK(30))
+    assert c.q.shape[1] == 30 and c.r.shape[0] == 30 and c.ind.shape[0] == shape[1]
+    assert rc.rel_diff_fro(c.to_mat(), a) < tol
+    t = qr.compress(CT.ADAPTIVE(tol))
+    oq = o.QR.compute_from(a).compress("ADAPTIVE", tol)
+    assert t.rank() == oq.rank() and t.rank() < min(shape)
+    assert rc.rel_diff_fro(t.to_mat(), a) < 5 * tol
+    cid = t.column_id()
+    assert rc.rel_diff_fro(cid.to_mat(), a) < 5 * tol
+    ap = npy(rc.apply_permutation(a, cid.get_col_ind(), rc.MatrixPermutationMode.COL))
+    for i in range(t.rank()):
+        assert rc.rel_diff_l2(ap[:, i].copy(), cid.get_c()[:, i].contiguous()) < tol
+    lq = rc.LQ.compute_from(a).compress(CT.ADAPTIVE(tol))
+    assert lq.rank() == o.LQ.compute_from(a).compress("ADAPTIVE", tol).rank()
+    assert rc.rel_diff_fro(lq.to_mat(), a) < 5 * tol
+    rid = lq.row_id()
+    assert rc.rel_diff_fro(rid.to_mat(), a) < 5 * tol
+    apr = npy(rc.apply_permutation(a, rid.get_row_ind(), rc.MatrixPermutationMode.ROW))
+    for i in range(lq.rank()):
+        assert rc.rel_diff_l2(apr[i].copy(), rid.get_r()[i].contiguous()) < tol
+    for ts, k in ((cid.two_sided_id(), t.rank()), (rid.two_sided_id(), lq.rank())):
+        assert rc.rel_diff_fro(ts.to_mat(), a) < 5 * tol
+        assert tuple(ts.x.shape) == (k, k)
+        mp = o.apply_permutation_matrix(o.apply_permutation_matrix(a, npy(ts.row_ind), "ROW"), npy(ts.col_ind), "COL")
+        assert np.all(np.abs(npy(ts.x) - mp[:k, :k]) < 10 * tol * np.abs(mp[:k, :k]))
+    # Apply (types.rs:25-29) on a matrix and on a vector
+    rhs = rng.standard_normal((shape[1], 3)).astype(dtype)
+    for dec in (cid, rid, cid.two_sided_id()):
+        full = npy(dec.to_mat()).astype(np.float64)
+        assert rel(npy(dec.dot(rhs)), full @ rhs) <= (1e-10 if dtype == np.float64 else 1e-4)
+        assert rel(npy(dec.dot(rhs[:, 0].copy())), full @ rhs[:, 0]) <= (1e-10 if dtype == np.float64 else 1e-4)
+
+
+def test_ids_match_golden_factor_by_factor():
+    g = golden("cfg1_id.npz")
+    a = golden("cfg1_sketch_rsvd.npz")["a"]
+    full = rc.QR.compute_from(a)
+    full_lq = rc.LQ.compute_from(a)
+    for ct, tag in ((CT.RANK(32), "rank32"), (CT.ADAPTIVE(1e-4), "tol1e4")):
+        qrc = full.compress(ct)
+        k = int(g[f"{tag}_rank"])
+        assert qrc.rank() == k
+        assert np.array_equal(npy(qrc.ind)[:k], g[f"{tag}_ind"][:k])
+        cid = qrc.column_id()
+        assert rel(npy(cid.c), g[f"{tag}_c"]) <= 1e-10
+        # Z solves R11 Z12 = R12 with cond(R11) ~ 1/tol: compare through the action on A's columns
+        assert rel(npy(cid.c) @ npy(cid.z), g[f"{tag}_c"] @ g[f"{tag}_z"]) <= 1e-10
+        assert rel(npy(cid.z)[:, npy(cid.col_ind)[:k]], np.eye(k)) <= 1e-12
+        ts = cid.two_sided_id()
+        assert np.array_equal(npy(ts.row_ind)[:k], g[f"{tag}_ts_row_ind"][:k])
+        assert rel(npy(ts.x), g[f"{tag}_ts_x"]) <= 1e-10
+        assert rel(npy(ts.to_mat()), g[f"{tag}_ts_c"] @ g[f"{tag}_ts_x"] @ g[f"{tag}_ts_r"]) <= 1e-9
+        lqc = full_lq.compress(ct)
+        kl = int(g[f"{tag}_lq_rank"])
+        assert lqc.rank() == kl
+        assert np.array_equal(npy(lqc.ind)[:kl], g[f"{tag}_lq_ind"][:kl])
+        rid = lqc.row_id()
+        assert rel(npy(rid.r), g[f"{tag}_rid_r"]) <= 1e-10
+        assert rel(npy(rid.to_mat()), g[f"{tag}_rid_x"] @ g[f"{tag}_rid_r"]) <= 1e-10
+        ts2 = rid.two_sided_id()
+        assert np.array_equal(npy(ts2.col_ind)[:kl], g[f"{tag}_ts2_col_ind"][:kl])
+        assert rel(npy(ts2.x), g[f"{tag}_ts2_x"]) <= 1e-10
+
+
+def test_full_rank_shortcuts_and_error_behaviour():
+    rng = np.random.default_rng(8)
+    a = rng.standard_normal((40, 12))
+    qr = rc.QR.compute_from(a)           # rank == ncols: src/qr.rs:274-281
+    cid = qr.column_id()
+    assert rel(npy(cid.to_mat()), a) <= 1e-13
+    ocid = o.QR.compute_from(a).column_id()
+    assert rel(npy(cid.c), ocid.c) <= 1e-12 and np.array_equal(npy(cid.z), ocid.z)
+    lq = rc.LQ.compute_from(a.T.copy())  # rank == nrows: src/qr.rs:367-374
+    rid = lq.row_id()
+    assert rel(npy(rid.to_mat()), a.T) <= 1e-13
+    with pytest.raises(rc.CompressionError):  # src/qr.rs:196-199
+        rc.QR.compute_from(np.eye(6)).compress(CT.ADAPTIVE(1e-3))
+    with pytest.raises(rc.CompressionError):  # src/svd.rs:97-100
+        rc.SVD.compute_from(np.eye(6)).compress(CT.ADAPTIVE(1e-3))
+    with pytest.raises(AssertionError):       # src/qr.rs:188
+        qr.compress(CT.ADAPTIVE(1.5))
+    big = qr.compress(CT.RANK(1000))          # rank is clipped: src/qr.rs:172-174
+    assert big.rank() == 12
+
+
+# ---------------------------------------------------------------- sampling (a4, a9, a12, a19, a20)
+def test_sketch_rsvd_and_range_qr_match_golden():
+    g = golden("cfg1_sketch_rsvd.npz")
+    a, omega, k, p = g["a"], g["omega"], int(g["k"]), int(g["p"])
+    q = rc.sample_range_by_rank(a, k, p, omega)
+    assert rel(npy(q), g["q_sample"]) <= 1e-10
+    qp = rc.sample_range_power_iteration(a, k, p, 2, omega)
+    assert rel(npy(qp), g["q_power"]) <= 1e-10
+    assert rel(npy(rc.sample_range_power_iteration(a, k, p, 1, omega)), g["q_power"]) <= 1e-10  # the shadowing quirk
+    assert rel(npy(rc.sample_range_power_iteration(a, k, p, 0, omega)), g["q_sample"]) <= 1e-10
+    svd = rc.SVD.compute_from_range_estimate(q, a)
+    assert np.abs(npy(svd.s) - g["s"]).max() / g["s"][0] <= 1e-12
+    u, vt = sign_normalise(npy(svd.u), npy(svd.vt))
+    assert rel(u, g["u"]) <= 1e-8 and rel(vt, g["vt"]) <= 1e-8
+    assert rel(npy(svd.to_mat()), g["u"] @ np.diag(g["s"]) @ g["vt"]) <= 1e-10
+    qr = rc.QR.compute_from_range_estimate(q, a)
+    assert np.array_equal(npy(qr.ind), g["qr_ind"])
+    assert rel(npy(qr.r), g["qr_r"]) <= 1e-10 and rel(npy(qr.q), g["qr_q"]) <= 1e-10
+    cid = qr.column_id()
+    assert rel(npy(cid.c), g["id_c"]) <= 1e-10 and rel(npy(cid.z), g["id_z"]) <= 1e-9
+
+
+def test_fused_rsvd_id_equals_the_separate_calls():
+    import ctypes
+
+    from rusty_compression_amd import _lib
+
+    g = golden("cfg1_sketch_rsvd.npz")
+    a = torch.from_numpy(g["a"]).cuda()
+    omega = torch.from_numpy(g["omega"]).cuda()
+    m, n = a.shape
+    k, p = int(g["k"]), int(g["p"])
+    mk = lambda r, c: torch.empty((r, c), dtype=torch.float64, device="cuda")  # noqa: E731
+    rq, u, vt, qq, qr_, cc, zz = mk(m, k), mk(m, k), mk(k, n), mk(m, k), mk(k, n), mk(m, k), mk(k, n)
+    s = torch.empty(k, dtype=torch.float64, device="cuda")
+    ind = torch.empty(n, dtype=torch.int64, device="cuda")
+    out = _lib.rc_rsvd_id_out(_lib.mat(rq), _lib.mat(u), ctypes.c_void_p(s.data_ptr()), _lib.mat(vt), _lib.mat(qq), _lib.mat(qr_),
+                              ctypes.c_void_p(ind.data_ptr()), _lib.mat(cc), _lib.mat(zz))
+    _lib.default_context().call("rc_rsvd_id_f64", _lib.mat(a), ctypes.c_int64(k), ctypes.c_int64(p), _lib.mat(omega), ctypes.c_uint64(0), ctypes.byref(out))
+    assert rel(npy(rq), g["q_sample"]) <= 1e-10
+    assert np.abs(npy(s) - g["s"]).max() / g["s"][0] <= 1e-12
+    un, vtn = sign_normalise(npy(u), npy(vt))
+    assert rel(un, g["u"]) <= 1e-8 and rel(vtn, g["vt"]) <= 1e-8
+    assert np.array_equal(npy(ind), g["qr_ind"])
+    assert rel(npy(qr_), g["qr_r"]) <= 1e-10 and rel(npy(qq), g["qr_q"]) <= 1e-10
+    assert rel(npy(cc), g["id_c"]) <= 1e-10 and rel(npy(zz), g["id_z"]) <= 1e-9
+
+
+def test_adaptive_sampling_matches_golden_history():
+    """examples/adaptive_sampling.rs call sequence; src/random_sampling.rs:223-274."""
+    g = golden("adaptive_500x200.npz")
+    a = g["a"]
+    q, res = rc.sample_range_adaptive(a, 1e-5, 5, g["omegas"])
+    assert [r for r, _ in res] == g["hist_rank"].tolist()
+    assert np.allclose([e for _, e in res], g["hist_res"], rtol=1e-6)
+    assert rel(npy(q), g["q"]) <= 1e-8
+    qr = rc.QR.compute_from_range_estimate(q, a)
+    err = rc.rel_diff_fro(qr.to_mat(), a)
+    assert abs(err - float(g["rel_err"])) <= 1e-9 and err < 1e-4
+    # device-generated Omega: same statistical behaviour, different samples
+    q2, res2 = rc.sample_range_adaptive(a, 1e-5, 5, rc.Rng(5))
+    assert q2.shape[1] % 5 == 0 and abs(q2.shape[1] - q.shape[1]) <= 25
+    assert rc.rel_diff_fro(rc.QR.compute_from_range_estimate(q2, a).to_mat(), a) < 1e-4
+    assert np.abs(npy(q2).T @ npy(q2) - np.eye(q2.shape[1])).max() < 1e-10
+    with pytest.raises(rc.CompressionError):  # capacity exhausted before the tolerance
+        rc.sample_range_adaptive(a, 1e-9, 5, rc.Rng(5), max_rank=20)
+
+
+def test_max_col_norm_and_rel_diff():
+    rng = np.random.default_rng(2)
+    for dtype in (np.float64, np.float32):
+        y = rng.standard_normal((300, 17)).astype(dtype)
+        assert abs(rc.max_col_norm(y) - float(o.max_col_norm(y))) <= (1e-12 if dtype == np.float64 else 1e-4)
+        z = y + (1e-3 * rng.standard_normal(y.shape)).astype(dtype)
+        assert abs(rc.rel_diff_fro(z, y) - o.rel_diff_fro(z, y)) <= (1e-12 if dtype == np.float64 else 1e-6)
+        assert abs(rc.rel_diff_l2(z[:, 0].copy(), y[:, 0].copy()) - o.rel_diff_l2(z[:, 0], y[:, 0])) <= (1e-12 if dtype == np.float64 else 1e-6)
+
+
+def test_random_test_matrix_generators():
+    a = rc.random_approximate_low_rank_matrix((120, 70), 1.0, 1e-6, rc.Rng(1))
+    s = np.linalg.svd(npy(a), compute_uv=False)
+    assert rel(s, np.geomspace(1e-6, 1.0, 70)[::-1]) <= 1e-9  # src/random_matrix.rs:84-92
+    u = npy(rc.random_orthogonal_matrix((90, 30), rc.Rng(2)))
+    assert np.abs(u.T @ u - np.eye(30)).max() <= 1e-12
+    w = npy(rc.random_orthogonal_matrix((30, 90), rc.Rng(2)))
+    assert np.abs(w @ w.T - np.eye(30)).max() <= 1e-12
