@@ -158,6 +158,9 @@ def main():
     t1 = time.perf_counter()
     if dist is not None:
         dist.barrier()
+    # every captured tall-skinny fast path must have certified itself (no fallback exists inside a graph)
+    health = [ln["ctx"].get_health() for ln in lanes]
+    assert not any(health), f"fast-path certificate failed during the timed region: {health}"
     elapsed = t1 - t0
     if dist is not None:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")

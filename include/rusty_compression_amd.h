@@ -97,6 +97,18 @@ rc_status rc_graph_end_capture(rc_context *ctx, void **graph_exec);
 rc_status rc_graph_launch(rc_context *ctx, void *graph_exec);
 rc_status rc_graph_destroy(rc_context *ctx, void *graph_exec);
 
+/* Options.  RC_OPT_TALL_SKINNY_FAST_PATH (default 1): tall-skinny pivoted QR / QR inside
+ * the SVD run as CholeskyQR2 + an LDS-resident pivoted QR of the small factor + a sign fix
+ * that restores LAPACK's Householder sign convention; the path certifies itself
+ * (positive Cholesky pivots, ||Q1^T Q1 - I|| small) and the call falls back to the plain
+ * Householder chain (exact ?geqp3/?orgqr operation order) when the certificate fails.
+ * 0 forces the Householder chain.  While a hipGraph is being captured no fallback is
+ * possible: failures are OR-ed into a health word instead, which rc_get_health returns
+ * and clears (0 = every captured fast path certified itself). */
+enum { RC_OPT_TALL_SKINNY_FAST_PATH = 1 };
+rc_status rc_set_option(rc_context *ctx, int32_t option, int64_t value);
+rc_status rc_get_health(rc_context *ctx, int32_t *word);
+
 /* Stage / kernel timers: HIP events recorded on the context's stream around the
  * dominant kernels and pipeline stages (used by bench.py for the roofline line).
  * rc_profile_count / rc_profile_get synchronise the stream. */

@@ -17,6 +17,7 @@ LIB_PATH = os.path.join(_HERE, "librusty_compression_amd.so")
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "rusty_compression_amd.h")
 
 # status codes (include/rusty_compression_amd.h) <-> RustyCompressionError (reference src/types.rs:11-21)
+RC_OPT_TALL_SKINNY_FAST_PATH = 1
 RC_OK, RC_LINALG_ERROR, RC_COMPRESSION_ERROR, RC_LAYOUT_ERROR, RC_PIVOTED_QR_ERROR, RC_INVALID_ARGUMENT, RC_RUNTIME_ERROR = range(7)
 
 
@@ -169,6 +170,16 @@ class Context:
 
     def synchronize(self):
         self.check(lib().rc_synchronize(self._h))
+
+    def set_option(self, option: int, value: int):
+        """rc_set_option; option ids: RC_OPT_TALL_SKINNY_FAST_PATH = 1."""
+        self.check(lib().rc_set_option(self._h, ctypes.c_int32(option), ctypes.c_int64(value)))
+
+    def get_health(self) -> int:
+        """rc_get_health: failure bits of fast paths that could not fall back (graph capture); clears them."""
+        w = ctypes.c_int32(0)
+        self.check(lib().rc_get_health(self._h, ctypes.byref(w)))
+        return int(w.value)
 
     def reserve_workspace(self, nbytes: int):
         self.check(lib().rc_reserve_workspace(self._h, ctypes.c_size_t(nbytes)))

@@ -226,7 +226,9 @@ static void launch_cfg(rc_context *c, GemmArgs<T> g) {
     // split K until the grid covers the 256 CUs about twice (only worth it for deep K)
     int splits = 1;
     const int64_t ksteps = cdiv(g.K, BK);
-    while (tiles * splits < 384 && splits < 16 && ksteps / (splits * 2) >= 16) splits *= 2;
+    // (tiny outputs with a deep reduction -- the n x n Gram matrices of the CholeskyQR passes --
+    //  need up to 128 slabs to reach every CU)
+    while (tiles * splits < 384 && splits < 128 && ksteps / (splits * 2) >= (tiles >= 32 ? 16 : 4)) splits *= 2;
     g.kchunk = cdiv(cdiv(g.K, splits), BK) * BK;
     splits = (int)cdiv(g.K, g.kchunk);
     if (splits < 1) splits = 1;
@@ -255,7 +257,8 @@ static void launch_shape(rc_context *c, const GemmArgs<T> &g) {
     // Skinny outputs (the sketch Y = A Omega has N = k + p ~ 69..133; the range
     // projection B = Q^H A has M = k ~ 64..128) get tiles that cover the short
     // side once, so the long operand streams from HBM exactly once.
-    if (g.N <= 80) launch_cfg<T, ALAY, BLAY, 128, 80, 16, 4, 1>(c, g);
+    if (g.M <= 144 && g.N <= 144 && g.M > 80 && g.N > 80) launch_cfg<T, ALAY, BLAY, 144, 144, 16, 3, 3>(c, g);
+    else if (g.N <= 80) launch_cfg<T, ALAY, BLAY, 128, 80, 16, 4, 1>(c, g);
     else if (g.N <= 144) launch_cfg<T, ALAY, BLAY, 128, 144, 16, 4, 1>(c, g);
     else if (g.M <= 80) launch_cfg<T, ALAY, BLAY, 80, 128, 16, 1, 4>(c, g);
     else if (g.M <= 144) launch_cfg<T, ALAY, BLAY, 144, 128, 16, 1, 4>(c, g);

@@ -361,6 +361,52 @@ __global__ __launch_bounds__(256) void k_form_q_general(Mat<T> w, const int64_t 
     }
 }
 
+// ---- compact-WY form-Q for tall matrices: Q = (I - V T V^T) [I ; 0] as three GEMMs ----
+// vm(i, j) = v_j(i): zeros above the diagonal, one on it, reflector below
+template <typename T>
+__global__ __launch_bounds__(256) void k_extract_v(Mat<T> w, const int64_t *jpvt, Mat<T> vm) {
+    const int64_t j = blockIdx.y;
+    const T *col = w.p + jpvt[j] * w.cs;
+    T *out = vm.p + j * vm.cs;
+    for (int64_t i = blockIdx.x * 256 + threadIdx.x; i < vm.rows; i += (int64_t)gridDim.x * 256)
+        out[i] = (i < j) ? (T)0 : (i == j) ? (T)1 : col[i];
+}
+// T = D (I + striu(S) D)^{-1}, D = diag(tau), S = V^T V  (tau_j == 0, i.e. H_j = I, needs
+// no special case).  Built column by column with the ?larft recurrence
+//   T[0:j, j] = -tau_j * T[0:j, 0:j] * S[0:j, j],  T[j, j] = tau_j
+// by ONE workgroup: thread i owns row i of T (kept in global/L2, written once per
+// column), the current S column is broadcast through LDS.
+template <typename T>
+__global__ __launch_bounds__(1024) void k_build_t(Mat<T> sgram, const T *tau, Mat<T> tm) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    T *svec = reinterpret_cast<T *>(smem_raw);  // k entries
+    T *trow = svec + tm.rows;                   // k x (k | 1) : T in LDS when it fits, else unused
+    const int k = (int)tm.rows;
+    const int ld = k | 1;
+    const int tid = threadIdx.x;
+    for (int e = tid; e < k * ld; e += 1024) trow[e] = 0;
+    __syncthreads();
+    for (int j = 0; j < k; ++j) {
+        for (int l = tid; l < j; l += 1024) svec[l] = sgram.at(l, j);
+        __syncthreads();
+        const T tj = tau[j];
+        for (int i = tid; i <= j; i += 1024) {
+            if (i == j) {
+                trow[i * ld + j] = tj;
+            } else {
+                T acc = 0;
+                for (int l = i; l < j; ++l) acc += trow[i * ld + l] * svec[l];
+                trow[i * ld + j] = -tj * acc;
+            }
+        }
+        __syncthreads();
+    }
+    for (int e = tid; e < k * k; e += 1024) {
+        int i = e % k, j = e / k;
+        tm.at(i, j) = trow[i * ld + j];
+    }
+}
+
 template <typename T>
 void form_q(rc_context *c, Mat<T> w, const int64_t *jpvt, const T *tau, int64_t k, Mat<T> qw) {
     RC_REQUIRE(w.rs == 1 && qw.rs == 1 && qw.rows == w.rows, RC_LAYOUT_ERROR, "form_q: column-major operands required");
@@ -369,6 +415,32 @@ void form_q(rc_context *c, Mat<T> w, const int64_t *jpvt, const T *tau, int64_t 
     const unsigned grid = (unsigned)qw.cols;
     if (k <= 0) { fill_identity(c, qw); return; }
     ProfScope ps(c, "op:form_q %lldx%lld k=%lld", (long long)m, (long long)qw.cols, (long long)k);
+    if (m >= 2048 && k >= 16 && ((size_t)k + (size_t)k * (k | 1)) * sizeof(T) <= 160 * 1024 - 1024) {
+        // tall: three MFMA GEMMs instead of k dependent reflector applications per column
+        ArenaMark mark(c);
+        const int64_t kq = qw.cols;
+        Mat<T> vm = colmajor(c->alloc<T>((size_t)m * k), m, k, m);
+        hipLaunchKernelGGL(k_extract_v<T>, dim3((unsigned)std::min<int64_t>(cdiv(m, 256), 64), (unsigned)k), dim3(256), 0, c->stream, w, jpvt, vm);
+        Mat<T> sg = rowmajor(c->alloc<T>((size_t)k * k), k, k, k);
+        gemm<T>(c, 1, vm.t(), vm, 0, sg);
+        Mat<T> tm = colmajor(c->alloc<T>((size_t)k * k), k, k, k);
+        {
+            const size_t lds = ((size_t)k + (size_t)k * (k | 1)) * sizeof(T);
+            RC_REQUIRE(lds <= 160 * 1024 - 1024, RC_INVALID_ARGUMENT, "form_q: block of %lld reflectors does not fit the LDS T-builder", (long long)k);
+            auto kern = k_build_t<T>;
+            static bool attr_set[64] = {};
+            if (!attr_set[c->device & 63]) {
+                RC_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024));
+                attr_set[c->device & 63] = true;
+            }
+            hipLaunchKernelGGL(kern, dim3(1), dim3(1024), lds, c->stream, sg, tau, tm);
+        }
+        Mat<T> w2 = rowmajor(c->alloc<T>((size_t)k * kq), k, kq, kq);
+        gemm<T>(c, 1, tm, vm.sub(0, std::min(kq, m), 0, k).t(), 0, w2);
+        fill_identity(c, qw);
+        gemm<T>(c, -1, vm, w2, 1, qw);
+        return;
+    }
     if (m <= 256 * 2) hipLaunchKernelGGL((k_form_q<T, 2>), dim3(grid), dim3(256), 0, c->stream, w, jpvt, tau, k, qw);
     else if (m <= 256 * 8) hipLaunchKernelGGL((k_form_q<T, 8>), dim3(grid), dim3(256), 0, c->stream, w, jpvt, tau, k, qw);
     else if (m <= 256 * 32) hipLaunchKernelGGL((k_form_q<T, 32>), dim3(grid), dim3(256), 0, c->stream, w, jpvt, tau, k, qw);
@@ -383,13 +455,51 @@ void form_q(rc_context *c, Mat<T> w, const int64_t *jpvt, const T *tau, int64_t 
 // ---------------------------------------------------------------------------
 template <typename T>
 __global__ __launch_bounds__(256) void k_trsm_upper(Mat<T> t, Mat<T> b) {
+    // Blocked back substitution: 16 rows of X per thread in registers, the 16 x 16
+    // tiles of the triangle staged through LDS (every thread reads the same tile
+    // entry: an LDS broadcast), the 16 X values of a finished block re-read with 16
+    // independent, coalesced global loads.
+    constexpr int NB = 16;
+    __shared__ T tile[NB][NB + 1];
     const int64_t col = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
-    if (col >= b.cols) return;
+    const bool active = col < b.cols;
     const int64_t k = t.rows;
-    for (int64_t i = k - 1; i >= 0; --i) {
-        T s = b.at(i, col);
-        for (int64_t jj = i + 1; jj < k; ++jj) s -= t.at(i, jj) * b.at(jj, col);
-        b.at(i, col) = s / t.at(i, i);
+    const int64_t nblk = (k + NB - 1) / NB;
+    const int ti = threadIdx.x / NB, tj = threadIdx.x % NB;
+    for (int64_t bi = nblk - 1; bi >= 0; --bi) {
+        const int64_t r0 = bi * NB;
+        T acc[NB];
+#pragma unroll
+        for (int ii = 0; ii < NB; ++ii) acc[ii] = (active && r0 + ii < k) ? b.at(r0 + ii, col) : (T)0;
+        for (int64_t bj = nblk - 1; bj >= bi; --bj) {
+            const int64_t c0 = bj * NB;
+            __syncthreads();
+            tile[ti][tj] = (r0 + ti < k && c0 + tj < k) ? t.at(r0 + ti, c0 + tj) : (T)0;
+            __syncthreads();
+            if (bj > bi) {
+                T x[NB];
+#pragma unroll
+                for (int jj = 0; jj < NB; ++jj) x[jj] = (active && c0 + jj < k) ? b.at(c0 + jj, col) : (T)0;
+#pragma unroll
+                for (int jj = 0; jj < NB; ++jj)
+#pragma unroll
+                    for (int ii = 0; ii < NB; ++ii) acc[ii] -= tile[ii][jj] * x[jj];
+            } else {
+#pragma unroll
+                for (int ii = NB - 1; ii >= 0; --ii) {
+                    if (r0 + ii < k) {
+                        acc[ii] /= tile[ii][ii];
+#pragma unroll
+                        for (int i2 = 0; i2 < ii; ++i2) acc[i2] -= tile[i2][ii] * acc[ii];
+                    }
+                }
+            }
+        }
+        if (active) {
+#pragma unroll
+            for (int ii = 0; ii < NB; ++ii)
+                if (r0 + ii < k) b.at(r0 + ii, col) = acc[ii];
+        }
     }
 }
 template <typename T>

@@ -1,17 +1,28 @@
 // Small-core SVD for gfx950: one-sided (Hestenes) Jacobi on a square n x n
-// matrix, n <= 1024, inside ONE workgroup.
+// matrix, n <= 1024.
 //
 // Replaces the dense core of LAPACK ?gesdd as the reference reaches it through
 // ndarray-linalg `svddc_into(JobSvd::Some)` (/root/reference/src/compute_svd.rs:19).
 // The tall/wide input is first reduced to its square triangular factor by the
-// Householder QR of kernels_qr.hip (rc_api.hip: compute_svd), so this kernel only
+// Householder QR of kernels_qr.hip (rc_api.hip: svd_core), so this file only
 // ever sees min(m, n) x min(m, n).  One-sided Jacobi computes every singular
 // value to high RELATIVE accuracy, which is what the f64 <= 1e-12 round-trip
 // bound of the reference tests (src/svd.rs:290-297) needs.
 //
-// Mapping: round-robin (circle) ordering gives n/2 independent column pairs per
-// round; 16 lanes (a quarter wave) own one pair, so a 1024-thread workgroup
-// rotates 64 pairs per pass with quarter-wave shuffles and one barrier per round.
+// MI355X mapping
+//  * k_jacobi_lds: the whole core lives in the 160 KiB LDS of ONE CU (128 x 128
+//    f64 = 128 KiB).  Round-robin (circle) ordering gives n/2 independent column
+//    pairs per round; 16 lanes (one DPP row) own a pair, keep both columns in
+//    registers between the three dot products and the rotation (one LDS read +
+//    one LDS write of the pair per round), reduce with DPP row operations (no
+//    LDS traffic for the reductions) and the 1024-thread workgroup needs ONE
+//    barrier per round.  The right singular vectors are NOT accumulated here:
+//    every rotation (c, s) is appended to a log in HBM (write-only stream).
+//  * k_jacobi_replay_v: V = product of the logged rotations.  Rotations act on
+//    columns, so every ROW of V is independent: one wave per row keeps its row
+//    in LDS and streams the log -- no barrier at all, 128 waves in parallel.
+//  * k_jacobi_global: fallback for cores that do not fit LDS (n <= 1024),
+//    everything in L2-resident global memory.
 #include "rc_common.hpp"
 
 namespace rc {
@@ -20,51 +31,225 @@ template <typename T> struct JEps;
 template <> struct JEps<double> { static __device__ inline double eps() { return 1.1102230246251565e-16; } };
 template <> struct JEps<float> { static __device__ inline float eps() { return 5.9604644775390625e-08f; } };
 
-template <typename T>
-__device__ inline T qsum16(T v) {
-#pragma unroll
-    for (int off = 8; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+// ---- sum over the 16 lanes of a DPP row; every lane gets the total -------------
+__device__ inline float dpp_row_sum(float v) {
+    int x;
+    x = __builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xF, 0xF, true);  // quad_perm [1,0,3,2]
+    v += __int_as_float(x);
+    x = __builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xF, 0xF, true);  // quad_perm [2,3,0,1]
+    v += __int_as_float(x);
+    x = __builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x141, 0xF, 0xF, true);  // row_half_mirror
+    v += __int_as_float(x);
+    x = __builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x140, 0xF, 0xF, true);  // row_mirror
+    v += __int_as_float(x);
+    return v;
+}
+template <int CTRL>
+__device__ inline double dpp_mov64(double v) {
+    long long b = __double_as_longlong(v);
+    int lo = (int)(b & 0xffffffffLL), hi = (int)(b >> 32);
+    int rlo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xF, 0xF, true);
+    int rhi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xF, 0xF, true);
+    return __longlong_as_double(((long long)rhi << 32) | (unsigned int)rlo);
+}
+__device__ inline double dpp_row_sum(double v) {
+    v += dpp_mov64<0xB1>(v);   // quad_perm [1,0,3,2]
+    v += dpp_mov64<0x4E>(v);   // quad_perm [2,3,0,1]
+    v += dpp_mov64<0x141>(v);  // row_half_mirror
+    v += dpp_mov64<0x140>(v);  // row_mirror
     return v;
 }
 
-// g, v: column-major n x n (cs = ld).  On exit uc/vc hold the singular vectors
-// sorted by descending singular value, s the singular values.
-template <typename T>
-__global__ __launch_bounds__(1024) void k_jacobi_svd(Mat<T> g, Mat<T> v, Mat<T> uc, T *s, Mat<T> vc, int max_sweeps) {
-    __shared__ int sh_rot;
-    __shared__ T sig[1024];
-    __shared__ int order[1024];
-    const int tid = threadIdx.x;
-    const int l16 = tid & 15, grp = tid >> 4;  // 64 groups of 16 lanes
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() also waits for
+// outstanding GLOBAL stores (vmcnt(0)); the rotation-log stores are write-only and
+// must stay in flight across rounds, so the round barrier waits for lgkmcnt alone.
+__device__ inline void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+// circle-method pairing: round r of N-1 (N even), pair slot pi of N/2
+__device__ inline void rr_pair(int N, int r, int pi, int &p, int &q) {
+    if (pi == 0) { p = N - 1; q = r; }
+    else { p = (r + pi) % (N - 1); q = (r - pi + (N - 1)) % (N - 1); }
+    if (p > q) { int t = p; p = q; q = t; }
+}
+
+// one rotation record of the log
+template <typename T> struct Rot { T c, s; };
+
+// ---------------------------------------------------------------------------
+// LDS-resident one-sided Jacobi.  NE = ceil(n / 16) rows per lane (compile time).
+//   g      : n x n column-major input (global), destroyed
+//   log    : [max_sweeps][N-1][N/2] rotations (c = 1, s = 0 where none)
+//   sweeps : number of sweeps performed (device scalar out)
+//   uc, s  : left singular vectors / singular values, sorted descending
+//   order  : order[j] = sorted position of original column j (for the V replay)
+// ---------------------------------------------------------------------------
+template <typename T, int NE>
+__global__ __launch_bounds__(1024) void k_jacobi_lds(Mat<T> g, Rot<T> *log, int *sweeps_out, Mat<T> uc, T *s, int *order_out, int max_sweeps) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     const int n = (int)g.rows;
-    const int N = (n + 1) & ~1;  // padded to even; column n (if any) is a dummy
+    const int ld = n | 1;  // odd pitch: column starts spread over all banks
+    T *G = reinterpret_cast<T *>(smem_raw);
+    T *sig = G + (size_t)ld * n;
+    int *order = reinterpret_cast<int *>(sig + n);
+    volatile int *sh_rot_p = order + n;  // all LDS in the one dynamic array (keeps its base aligned)
+#define sh_rot (*sh_rot_p)
+    const int tid = threadIdx.x;
+    const int l16 = tid & 15, grp = tid >> 4;  // 64 groups (DPP rows) of 16 lanes
+    const int N = (n + 1) & ~1;
     const int npairs = N / 2;
     const T tol = sqrt((T)n) * JEps<T>::eps();
 
     for (int e = tid; e < n * n; e += 1024) {
         int i = e % n, j = e / n;
-        v.p[j * v.cs + i] = (i == j) ? (T)1 : (T)0;
+        G[j * ld + i] = g.p[(int64_t)j * g.cs + i];
     }
     __syncthreads();
 
+    int sweep = 0;
+    for (; sweep < max_sweeps; ++sweep) {
+        if (tid == 0) sh_rot = 0;
+        __syncthreads();
+        for (int r = 0; r < N - 1; ++r) {
+            for (int pi = grp; pi < npairs; pi += 64) {
+                int p, q;
+                rr_pair(N, r, pi, p, q);
+                Rot<T> rot{(T)1, (T)0};
+                if (q < n) {  // p < q; q == n is the dummy column of an odd n
+                    T *gp = G + p * ld, *gq = G + q * ld;
+                    T a[NE], b[NE];
+                    T app = 0, aqq = 0, apq = 0;
+#pragma unroll
+                    for (int e = 0; e < NE; ++e) {
+                        int i = l16 + 16 * e;
+                        a[e] = (i < n) ? gp[i] : (T)0;
+                        b[e] = (i < n) ? gq[i] : (T)0;
+                        app += a[e] * a[e]; aqq += b[e] * b[e]; apq += a[e] * b[e];
+                    }
+                    app = dpp_row_sum(app); aqq = dpp_row_sum(aqq); apq = dpp_row_sum(apq);
+                    if (apq != (T)0 && fabs(apq) > tol * sqrt(app) * sqrt(aqq)) {  // uniform over the 16 lanes
+                        const T zeta = (aqq - app) / ((T)2 * apq);
+                        const T t = copysign((T)1, zeta) / (fabs(zeta) + sqrt((T)1 + zeta * zeta));
+                        rot.c = (T)1 / sqrt((T)1 + t * t);
+                        rot.s = rot.c * t;
+#pragma unroll
+                        for (int e = 0; e < NE; ++e) {
+                            int i = l16 + 16 * e;
+                            if (i < n) {
+                                gp[i] = rot.c * a[e] - rot.s * b[e];
+                                gq[i] = rot.s * a[e] + rot.c * b[e];
+                            }
+                        }
+                        if (l16 == 0) sh_rot = 1;
+                    }
+                }
+                if (l16 == 0) log[((size_t)sweep * (N - 1) + r) * npairs + pi] = rot;
+            }
+            lds_barrier();  // pairs of one round are disjoint; the next round re-pairs the columns
+        }
+        const int rotated = sh_rot;
+        __syncthreads();
+        if (!rotated) { ++sweep; break; }
+    }
+    if (tid == 0) *sweeps_out = sweep;
+
+    // singular values = column norms; stable descending rank sort (gesdd order)
+    for (int j = grp; j < n; j += 64) {
+        const T *gj = G + j * ld;
+        T acc = 0;
+        for (int i = l16; i < n; i += 16) acc += gj[i] * gj[i];
+        acc = dpp_row_sum(acc);
+        if (l16 == 0) sig[j] = sqrt(acc);
+    }
+    __syncthreads();
+    for (int i = tid; i < n; i += 1024) {
+        int rank = 0;
+        const T si = sig[i];
+        for (int j = 0; j < n; ++j) rank += (sig[j] > si || (sig[j] == si && j < i)) ? 1 : 0;
+        order[i] = rank;
+        order_out[i] = rank;
+        s[rank] = si;
+    }
+    __syncthreads();
+    for (int j = grp; j < n; j += 64) {
+        const int dst = order[j];
+        const T sj = sig[j];
+        const T inv = sj > (T)0 ? (T)1 / sj : (T)0;
+        const T *gj = G + j * ld;
+        for (int i = l16; i < n; i += 16) uc.at(i, dst) = gj[i] * inv;
+    }
+#undef sh_rot
+}
+
+// ---------------------------------------------------------------------------
+// V = J_1 J_2 ... applied to I, row by row: one wave per row of V.
+// ---------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void k_jacobi_replay_v(int n, const Rot<T> *log, const int *sweeps, const int *order, Mat<T> vc) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    T *rows = reinterpret_cast<T *>(smem_raw);
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int row = blockIdx.x * 4 + wv;
+    if (row >= n) return;  // whole wave; no barriers in this kernel
+    T *v = rows + (size_t)wv * (n + 1);
+    const int N = (n + 1) & ~1, npairs = N / 2;
+    for (int j = lane; j < n; j += 64) v[j] = (j == row) ? (T)1 : (T)0;
+    const int ns = *sweeps;
+    for (int sw = 0; sw < ns; ++sw)
+        for (int r = 0; r < N - 1; ++r) {
+            const Rot<T> *lr = log + ((size_t)sw * (N - 1) + r) * npairs;
+            for (int pi = lane; pi < npairs; pi += 64) {
+                const Rot<T> rot = lr[pi];
+                if (rot.s != (T)0) {
+                    int p, q;
+                    rr_pair(N, r, pi, p, q);
+                    T a = v[p], b = v[q];
+                    v[p] = rot.c * a - rot.s * b;
+                    v[q] = rot.s * a + rot.c * b;
+                }
+            }
+            // a wave executes its LDS operations in order: the next round (other pairing of the
+            // same row) sees these writes without a barrier
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        }
+    for (int j = lane; j < n; j += 64) vc.at(row, order[j]) = v[j];
+}
+
+// ---------------------------------------------------------------------------
+// fallback: everything in (L2-resident) global memory, V accumulated in place
+// ---------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(1024) void k_jacobi_global(Mat<T> g, Mat<T> v, Mat<T> uc, T *s, Mat<T> vc, int max_sweeps) {
+    __shared__ int sh_rot;
+    __shared__ T sig[1024];
+    __shared__ int order[1024];
+    const int tid = threadIdx.x;
+    const int l16 = tid & 15, grp = tid >> 4;
+    const int n = (int)g.rows;
+    const int N = (n + 1) & ~1;
+    const int npairs = N / 2;
+    const T tol = sqrt((T)n) * JEps<T>::eps();
+
+    for (int e = tid; e < n * n; e += 1024) {
+        int i = e % n, j = e / n;
+        v.p[(int64_t)j * v.cs + i] = (i == j) ? (T)1 : (T)0;
+    }
+    __syncthreads();
     for (int sweep = 0; sweep < max_sweeps; ++sweep) {
         if (tid == 0) sh_rot = 0;
         __syncthreads();
         for (int r = 0; r < N - 1; ++r) {
             for (int pi = grp; pi < npairs; pi += 64) {
                 int p, q;
-                if (pi == 0) { p = N - 1; q = r; }
-                else { p = (r + pi) % (N - 1); q = (r - pi + (N - 1)) % (N - 1); }
-                if (p >= n || q >= n) continue;  // dummy column of an odd n
-                if (p > q) { int t = p; p = q; q = t; }
+                rr_pair(N, r, pi, p, q);
+                if (q >= n) continue;
                 T *gp = g.p + (int64_t)p * g.cs, *gq = g.p + (int64_t)q * g.cs;
                 T app = 0, aqq = 0, apq = 0;
                 for (int i = l16; i < n; i += 16) {
                     T a = gp[i], b = gq[i];
                     app += a * a; aqq += b * b; apq += a * b;
                 }
-                app = qsum16(app); aqq = qsum16(aqq); apq = qsum16(apq);
-                if (apq == (T)0 || fabs(apq) <= tol * sqrt(app) * sqrt(aqq)) continue;  // uniform over the 16 lanes
+                app = dpp_row_sum(app); aqq = dpp_row_sum(aqq); apq = dpp_row_sum(apq);
+                if (apq == (T)0 || fabs(apq) <= tol * sqrt(app) * sqrt(aqq)) continue;
                 const T zeta = (aqq - app) / ((T)2 * apq);
                 const T t = copysign((T)1, zeta) / (fabs(zeta) + sqrt((T)1 + zeta * zeta));
                 const T cs = (T)1 / sqrt((T)1 + t * t), sn = cs * t;
@@ -81,23 +266,20 @@ __global__ __launch_bounds__(1024) void k_jacobi_svd(Mat<T> g, Mat<T> v, Mat<T> 
                 }
                 if (l16 == 0) sh_rot = 1;
             }
-            __syncthreads();  // pairs of one round are disjoint; the next round re-pairs the columns
+            __syncthreads();
         }
         const int rotated = sh_rot;
         __syncthreads();
         if (!rotated) break;
     }
-
-    // singular values = column norms
     for (int j = grp; j < n; j += 64) {
         const T *gj = g.p + (int64_t)j * g.cs;
         T acc = 0;
         for (int i = l16; i < n; i += 16) { T a = gj[i]; acc += a * a; }
-        acc = qsum16(acc);
+        acc = dpp_row_sum(acc);
         if (l16 == 0) sig[j] = sqrt(acc);
     }
     __syncthreads();
-    // rank sort, descending, stable (gesdd returns S descending)
     for (int i = tid; i < n; i += 1024) {
         int rank = 0;
         const T si = sig[i];
@@ -118,14 +300,42 @@ __global__ __launch_bounds__(1024) void k_jacobi_svd(Mat<T> g, Mat<T> v, Mat<T> 
     }
 }
 
+template <typename T, int NE>
+static void launch_lds(rc_context *c, Mat<T> g, Mat<T> uc, T *s, Mat<T> vc, size_t lds, int max_sweeps) {
+    const int n = (int)g.rows, N = (n + 1) & ~1;
+    ArenaMark mark(c);
+    Rot<T> *log = c->alloc<Rot<T>>((size_t)max_sweeps * (N - 1) * (N / 2));
+    int *sweeps = c->alloc<int>(1);
+    int *order = c->alloc<int>((size_t)n);
+    auto kern = k_jacobi_lds<T, NE>;
+    static bool attr_set[64] = {};
+    if (!attr_set[c->device & 63]) {
+        RC_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 2048));
+        attr_set[c->device & 63] = true;
+    }
+    hipLaunchKernelGGL(kern, dim3(1), dim3(1024), lds, c->stream, g, log, sweeps, uc, s, order, max_sweeps);
+    const size_t lds_v = 4 * (size_t)(n + 1) * sizeof(T);
+    hipLaunchKernelGGL(k_jacobi_replay_v<T>, dim3((unsigned)((n + 3) / 4)), dim3(256), lds_v, c->stream, n, log, sweeps, order, vc);
+}
+
 template <typename T>
 void jacobi_svd(rc_context *c, Mat<T> g, Mat<T> vwork, Mat<T> uc, T *s, Mat<T> vc) {
     RC_REQUIRE(g.rows == g.cols && g.rs == 1 && vwork.rs == 1, RC_LAYOUT_ERROR, "jacobi_svd: square column-major core required");
     RC_REQUIRE(g.rows <= 1024, RC_INVALID_ARGUMENT, "compute_svd: min(m, n) = %lld > 1024 is not supported by the single-workgroup Jacobi core",
                (long long)g.rows);
-    if (g.rows == 0) return;
+    const int n = (int)g.rows;
+    if (n == 0) return;
     ProfScope ps(c, "op:jacobi_svd n=%lld", (long long)g.rows);
-    hipLaunchKernelGGL(k_jacobi_svd<T>, dim3(1), dim3(1024), 0, c->stream, g, vwork, uc, s, vc, 60);
+    const int max_sweeps = 30;
+    const size_t lds = ((size_t)(n | 1) * n + n) * sizeof(T) + (size_t)n * sizeof(int) + 64;
+    if (lds <= 160 * 1024 - 2048 - 64 && n <= 192) {
+        if (n <= 32) launch_lds<T, 2>(c, g, uc, s, vc, lds, max_sweeps);
+        else if (n <= 64) launch_lds<T, 4>(c, g, uc, s, vc, lds, max_sweeps);
+        else if (n <= 128) launch_lds<T, 8>(c, g, uc, s, vc, lds, max_sweeps);
+        else launch_lds<T, 12>(c, g, uc, s, vc, lds, max_sweeps);  // f32 up to n = 192 (the LDS bound is ~200)
+    } else {
+        hipLaunchKernelGGL(k_jacobi_global<T>, dim3(1), dim3(1024), 0, c->stream, g, vwork, uc, s, vc, 60);
+    }
 }
 
 template void jacobi_svd<double>(rc_context *, Mat<double>, Mat<double>, Mat<double>, double *, Mat<double>);

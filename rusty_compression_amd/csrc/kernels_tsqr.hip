@@ -1,0 +1,457 @@
+// Communication-avoiding QR / pivoted QR of TALL-SKINNY matrices (m >> n, n <= ~138 f64)
+// for gfx950.  Same results as the Householder chain of kernels_qr.hip (LAPACK ?geqp3 +
+// ?orgqr semantics, including the SIGNS of R's diagonal), organised for MI355X:
+//
+//   Y (m x n)  --CholeskyQR2-->  Y = Q1 R1        three MFMA GEMMs per pass (Gram, apply R^-1),
+//                                                  the n x n Cholesky + inverse in ONE workgroup's LDS
+//   R1 (n x n) --Householder QRCP in LDS-->  R1 P = Q2 R     (?laqp2 semantics: first-max pivot,
+//                                                  LAPACK norm down-dating / tol3z recompute)
+//   Q = Q1 Q2  (one GEMM),  then the Householder sign convention of LAPACK is re-imposed:
+//   the reflector representation of an orthonormal Q is unique, its signs d_j follow from an
+//   LU-type elimination on Q's top k x k block (d_j = -sgn of the j-th pivot candidate), so
+//   Q <- Q D, R <- D R reproduce ?geqp3/?orgqr exactly (tests: R to 1e-14 of LAPACK).
+//
+// Why: the m x n Householder chain needs ~2n dependent kernel launches that each stream the
+// whole trailing matrix through single CUs (measured 3.2 ms for 8192 x 133); here the only
+// serial parts act on n x n data inside one CU's LDS and everything O(m n^2) is a GEMM.
+// CholeskyQR2 is only valid while cond(Y)^2 * eps < 1: k_chol_inv certifies its own result
+// (positive pivots, ||Q1^T Q1 - I||_max small before the second pass) and raises a flag, on
+// which the caller falls back to the Householder chain (rc_api.hip).
+//
+// Replaces: ?geqp3 + ?orgqr on sketches (/root/reference/src/pivoted_qr.rs:81-183 as called
+// from src/random_sampling.rs:114) and the QR/LQ reduction inside ?gesdd (src/compute_svd.rs:19).
+#include "rc_common.hpp"
+
+namespace rc {
+
+static __host__ __device__ inline int64_t cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+template <typename T> struct TNum;
+template <> struct TNum<double> {
+    static __device__ inline double tol3z() { return 1.0536712127723509e-08; }
+    static __device__ inline double tiny() { return 1e-300; }
+};
+template <> struct TNum<float> {
+    static __device__ inline float tol3z() { return 2.44140625e-04f; }
+    static __device__ inline float tiny() { return 1e-30f; }
+};
+
+template <typename T>
+__device__ inline T wave_sum64(T v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+template <typename T>
+__device__ inline T row_sum16(T v) {  // sum over an aligned group of 16 lanes
+#pragma unroll
+    for (int off = 8; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+
+// ---------------------------------------------------------------------------
+// Cholesky G = R^T R (R upper) + R^{-1}, n x n in the LDS of one workgroup.
+//   flag bit 0: non-positive pivot (G not numerically SPD)
+//   flag bit 1: check_identity && max|G - I| > ident_tol  (first pass left Q1 too far from orthonormal)
+// ---------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(1024) void k_chol_inv(Mat<T> g, Mat<T> r_out, Mat<T> rinv_out, int check_identity, T ident_tol, int *flag) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    const int n = (int)g.rows;
+    const int ld = n | 1;
+    T *A = reinterpret_cast<T *>(smem_raw);  // A[i * ld + c]
+    T *svec = A + (size_t)n * ld;
+    __shared__ T red[16];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+
+    T dev = 0;
+    for (int e = tid; e < n * n; e += 1024) {
+        int i = e / n, c = e % n;
+        T v = g.at(i, c);
+        A[i * ld + c] = v;
+        dev = max(dev, fabs(v - ((i == c) ? (T)1 : (T)0)));
+    }
+    if (check_identity) {
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) dev = max(dev, __shfl_xor(dev, off, 64));
+        if (lane == 0) red[wv] = dev;
+        __syncthreads();
+        if (tid == 0) {
+            T mx = 0;
+            for (int k = 0; k < 16; ++k) mx = max(mx, red[k]);
+            if (!(mx <= ident_tol)) atomicOr(flag, 2);
+        }
+    }
+    __syncthreads();
+
+    // right-looking Cholesky, upper factor stored in the upper triangle of A
+    const int ti = tid >> 5, tc = tid & 31;
+    for (int j = 0; j < n; ++j) {
+        T d = A[j * ld + j];
+        if (!(d > (T)0)) {
+            if (tid == 0) atomicOr(flag, 1);
+            d = TNum<T>::tiny();
+        }
+        const T rjj = sqrt(d);
+        __syncthreads();  // everyone has read the pivot
+        for (int c = j + tid; c < n; c += 1024) A[j * ld + c] = (c == j) ? rjj : A[j * ld + c] / rjj;
+        __syncthreads();
+        for (int i = j + 1 + ti; i < n; i += 32) {
+            const T rji = A[j * ld + i];
+            for (int c = j + 1 + tc; c < n; c += 32)
+                if (c >= i) A[i * ld + c] -= rji * A[j * ld + c];
+        }
+        __syncthreads();
+    }
+    for (int e = tid; e < n * n; e += 1024) {
+        int i = e / n, c = e % n;
+        r_out.at(i, c) = (c >= i) ? A[i * ld + c] : (T)0;
+    }
+    __syncthreads();
+    // in-place inverse of the upper triangle, column by column:
+    //   X[0:j, j] = -x_jj * X[0:j, 0:j] R[0:j, j],  x_jj = 1 / r_jj
+    for (int j = 0; j < n; ++j) {
+        for (int l = tid; l < j; l += 1024) svec[l] = A[l * ld + j];
+        const T xjj = (T)1 / A[j * ld + j];
+        __syncthreads();
+        for (int i = tid; i <= j; i += 1024) {
+            if (i == j) {
+                A[j * ld + j] = xjj;
+            } else {
+                T acc = 0;
+                for (int l = i; l < j; ++l) acc += A[i * ld + l] * svec[l];
+                A[i * ld + j] = -xjj * acc;
+            }
+        }
+        __syncthreads();
+    }
+    for (int e = tid; e < n * n; e += 1024) {
+        int i = e / n, c = e % n;
+        rinv_out.at(i, c) = (c >= i) ? A[i * ld + c] : (T)0;
+    }
+}
+
+template <typename T>
+static size_t chol_lds(int64_t n) { return ((size_t)n * (n | 1) + (size_t)n) * sizeof(T); }
+
+template <typename T>
+static void chol_inv(rc_context *c, Mat<T> g, Mat<T> r, Mat<T> rinv, bool check_identity, T ident_tol, int *flag) {
+    auto kern = k_chol_inv<T>;
+    static bool attr_set[64] = {};
+    if (!attr_set[c->device & 63]) {
+        RC_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024));
+        attr_set[c->device & 63] = true;
+    }
+    hipLaunchKernelGGL(kern, dim3(1), dim3(1024), chol_lds<T>(g.rows), c->stream, g, r, rinv, check_identity ? 1 : 0, ident_tol, flag);
+}
+
+template <typename T>
+bool tsqr_supported(int64_t m, int64_t n) {
+    const size_t small_lds = ((size_t)n * (n | 1) + 4 * (size_t)n) * sizeof(T) + (size_t)n * sizeof(int) + 256;
+    return n >= 2 && m >= 4 * n && m >= 1024 && small_lds <= 160 * 1024 - 2048;
+}
+
+// Y = Q R by CholeskyQR2.  y: m x n (any strides, not modified), q: m x n (any strides),
+// r: n x n (upper, any strides).  *flag (device int) gets bits OR-ed in on failure.
+template <typename T>
+void tsqr_cholqr2(rc_context *c, Mat<T> y, Mat<T> q, Mat<T> r, int *flag) {
+    const int64_t m = y.rows, n = y.cols;
+    ProfScope ps(c, "op:cholqr2 %lldx%lld", (long long)m, (long long)n);
+    ArenaMark mark(c);
+    Mat<T> g = rowmajor(c->alloc<T>((size_t)n * n), n, n, n);
+    Mat<T> r1 = rowmajor(c->alloc<T>((size_t)n * n), n, n, n), r1i = rowmajor(c->alloc<T>((size_t)n * n), n, n, n);
+    Mat<T> r2 = rowmajor(c->alloc<T>((size_t)n * n), n, n, n), r2i = rowmajor(c->alloc<T>((size_t)n * n), n, n, n);
+    Mat<T> q1 = rowmajor(c->alloc<T>((size_t)m * n), m, n, n);  // row-major: coalesced GEMM epilogues
+    gemm<T>(c, 1, y.t(), y, 0, g);
+    chol_inv<T>(c, g, r1, r1i, false, 0, flag);
+    gemm<T>(c, 1, y, r1i, 0, q1);
+    gemm<T>(c, 1, q1.t(), q1, 0, g);
+    // after one pass ||Q1^T Q1 - I|| ~ cond(Y)^2 eps; the second pass is only accurate while that is << 1
+    chol_inv<T>(c, g, r2, r2i, true, (T)1e-2, flag);
+    gemm<T>(c, 1, q1, r2i, 0, q);
+    gemm<T>(c, 1, r2, r1, 0, r);
+}
+
+// ---------------------------------------------------------------------------
+// Householder QRCP (?laqp2 semantics) of an n x n matrix in the LDS of ONE workgroup,
+// plus the explicit orthogonal factor.  Columns are never moved (jp maps position -> column).
+//   rin  : n x n input (any strides)
+//   rout : kmax x n, rout(i, p) = (i <= p) ? R(i, jp[p]) : 0      (may be empty)
+//   q2   : n x q2.cols = H_0 ... H_{kmax-1} [I ; 0]                 (may be empty)
+// ---------------------------------------------------------------------------
+template <typename T, int NE>
+__global__ __launch_bounds__(1024) void k_qrcp_small(Mat<T> rin, int kmax, int pivot, int64_t *jpvt_out, Mat<T> rout, Mat<T> q2) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    const int n = (int)rin.rows;
+    const int ld = n | 1;
+    T *A = reinterpret_cast<T *>(smem_raw);  // column-major: A[c * ld + i]
+    T *vn1 = A + (size_t)n * ld;
+    T *vn2 = vn1 + n;
+    T *tau = vn2 + n;
+    int *jp = reinterpret_cast<int *>(tau + n);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int l16 = tid & 15, grp = tid >> 4;
+
+    for (int e = tid; e < n * n; e += 1024) {
+        int i = e % n, cc = e / n;
+        A[cc * ld + i] = rin.at(i, cc);
+    }
+    __syncthreads();
+    for (int p = grp; p < n; p += 64) {
+        T acc = 0;
+        for (int i = l16; i < n; i += 16) { T v = A[p * ld + i]; acc += v * v; }
+        acc = row_sum16(acc);
+        if (l16 == 0) { T nr = sqrt(acc); vn1[p] = nr; vn2[p] = nr; jp[p] = p; }
+    }
+    __syncthreads();
+
+    for (int j = 0; j < kmax; ++j) {
+        if (tid < 64) {  // wave 0: pivot search, "swap", reflector (?larfg)
+            if (pivot) {
+                T best = (T)-1;
+                int bi = 0x7fffffff;
+                for (int p = j + lane; p < n; p += 64) {
+                    T v = fabs(vn1[p]);
+                    if (v > best) { best = v; bi = p; }
+                }
+#pragma unroll
+                for (int off = 32; off > 0; off >>= 1) {
+                    T ob = __shfl_xor(best, off, 64);
+                    int oi = __shfl_xor(bi, off, 64);
+                    if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
+                }
+                const int pvt = (bi >= j && bi < n) ? bi : j;
+                if (lane == 0 && pvt != j) {
+                    int t = jp[pvt]; jp[pvt] = jp[j]; jp[j] = t;
+                    vn1[pvt] = vn1[j];
+                    vn2[pvt] = vn2[j];
+                }
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            }
+            T *col = A + jp[j] * ld;
+            const T alpha = col[j];
+            T acc = 0;
+            for (int i = j + 1 + lane; i < n; i += 64) { T v = col[i]; acc += v * v; }
+            acc = wave_sum64(acc);
+            const T xnorm = sqrt(acc);
+            if (xnorm == (T)0) {
+                if (lane == 0) tau[j] = 0;
+            } else {
+                const T beta = -copysign(hypot(alpha, xnorm), alpha);
+                const T scal = (T)1 / (alpha - beta);
+                for (int i = j + 1 + lane; i < n; i += 64) col[i] *= scal;
+                if (lane == 0) { tau[j] = (beta - alpha) / beta; col[j] = beta; }
+            }
+        }
+        __syncthreads();
+        {   // apply H_j to the remaining columns; one 16-lane group per column
+            const T tj = tau[j];
+            const T *vcol = A + jp[j] * ld;
+            for (int p = j + 1 + grp; p < n; p += 64) {
+                T *xcol = A + jp[p] * ld;
+                T x[NE], v[NE];
+                T dot = 0;
+#pragma unroll
+                for (int e = 0; e < NE; ++e) {
+                    int i = j + l16 + 16 * e;
+                    x[e] = 0; v[e] = 0;
+                    if (i < n) {
+                        x[e] = xcol[i];
+                        v[e] = (i == j) ? (T)1 : vcol[i];
+                        dot += v[e] * x[e];
+                    }
+                }
+                if (tj != (T)0) {
+                    dot = row_sum16(dot);
+                    const T f = tj * dot;
+#pragma unroll
+                    for (int e = 0; e < NE; ++e) {
+                        int i = j + l16 + 16 * e;
+                        if (i < n) { x[e] -= f * v[e]; xcol[i] = x[e]; }
+                    }
+                }
+                if (pivot) {
+                    const T xj = __shfl(x[0], lane & ~15, 64);
+                    const T vn = vn1[p];
+                    if (vn != (T)0) {
+                        T t = fabs(xj) / vn;
+                        T temp = (T)1 - t * t;
+                        temp = temp > (T)0 ? temp : (T)0;
+                        T rr = vn / vn2[p];
+                        T temp2 = temp * rr * rr;
+                        if (temp2 <= TNum<T>::tol3z()) {
+                            T ss = 0;
+#pragma unroll
+                            for (int e = 0; e < NE; ++e) {
+                                int i = j + l16 + 16 * e;
+                                if (i > j && i < n) ss += x[e] * x[e];
+                            }
+                            ss = row_sum16(ss);
+                            if (l16 == 0) { T nn = (j < n - 1) ? sqrt(ss) : (T)0; vn1[p] = nn; vn2[p] = nn; }
+                        } else if (l16 == 0) {
+                            vn1[p] = vn * sqrt(temp);
+                        }
+                    }
+                }
+            }
+        }
+        __syncthreads();
+    }
+
+    for (int p = tid; p < n; p += 1024) jpvt_out[p] = jp[p];
+    if (!rout.empty()) {
+        const int64_t total = rout.rows * rout.cols;
+        for (int64_t e = tid; e < total; e += 1024) {
+            int i = (int)(e / rout.cols), p = (int)(e % rout.cols);
+            rout.at(i, p) = (i <= p) ? A[jp[p] * ld + i] : (T)0;
+        }
+    }
+    if (!q2.empty()) {  // column cq of Q2: apply H_min(cq,kmax-1) ... H_0 to e_cq; A is read-only now
+        for (int cq = grp; cq < (int)q2.cols; cq += 64) {
+            T x[NE];
+#pragma unroll
+            for (int e = 0; e < NE; ++e) x[e] = (l16 + 16 * e == cq) ? (T)1 : (T)0;
+            for (int j = (cq < kmax - 1 ? cq : kmax - 1); j >= 0; --j) {
+                const T tj = tau[j];
+                if (tj == (T)0) continue;
+                const T *vcol = A + jp[j] * ld;
+                T v[NE];
+                T dot = 0;
+#pragma unroll
+                for (int e = 0; e < NE; ++e) {
+                    int i = l16 + 16 * e;
+                    v[e] = 0;
+                    if (i < n && i >= j) { v[e] = (i == j) ? (T)1 : vcol[i]; dot += v[e] * x[e]; }
+                }
+                dot = row_sum16(dot);
+                const T f = tj * dot;
+#pragma unroll
+                for (int e = 0; e < NE; ++e) x[e] -= f * v[e];
+            }
+#pragma unroll
+            for (int e = 0; e < NE; ++e) {
+                int i = l16 + 16 * e;
+                if (i < n) q2.at(i, cq) = x[e];
+            }
+        }
+    }
+}
+
+template <typename T>
+void qrcp_small(rc_context *c, Mat<T> rin, int64_t kmax, bool pivot, int64_t *jpvt, Mat<T> rout, Mat<T> q2) {
+    const int64_t n = rin.rows;
+    RC_REQUIRE(rin.rows == rin.cols, RC_INVALID_ARGUMENT, "qrcp_small: square input required");
+    const size_t lds = ((size_t)n * (n | 1) + 3 * (size_t)n) * sizeof(T) + (size_t)n * sizeof(int) + 64;
+    RC_REQUIRE(lds <= 160 * 1024 - 1024 && n <= 208, RC_INVALID_ARGUMENT, "qrcp_small: n = %lld does not fit LDS", (long long)n);
+    ProfScope ps(c, "op:qrcp_small n=%lld k=%lld", (long long)n, (long long)kmax);
+#define RC_QS(NE)                                                                                                      \
+    do {                                                                                                               \
+        auto kern = k_qrcp_small<T, NE>;                                                                               \
+        static bool attr_set[64] = {};                                                                                 \
+        if (!attr_set[c->device & 63]) {                                                                               \
+            RC_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024)); \
+            attr_set[c->device & 63] = true;                                                                           \
+        }                                                                                                              \
+        hipLaunchKernelGGL(kern, dim3(1), dim3(1024), lds, c->stream, rin, (int)kmax, pivot ? 1 : 0, jpvt, rout, q2);  \
+    } while (0)
+    if (n <= 64) RC_QS(4);
+    else if (n <= 144) RC_QS(9);
+    else RC_QS(13);
+#undef RC_QS
+}
+
+// ---------------------------------------------------------------------------
+// Householder sign convention: d_j such that Q D = H_0 ... H_{k-1} [I ; 0] with LAPACK's
+// reflectors (beta = -sign(alpha) |x|).  LU-type elimination on the top k x k block of Q.
+// ---------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(1024) void k_householder_signs(Mat<T> q, T *d) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    const int k = (int)q.cols;
+    const int ld = k | 1;
+    T *W = reinterpret_cast<T *>(smem_raw);  // W[i * ld + c]
+    const int tid = threadIdx.x;
+    for (int e = tid; e < k * k; e += 1024) {
+        int i = e % k, cc = e / k;
+        W[i * ld + cc] = q.at(i, cc);
+    }
+    __syncthreads();
+    const int ti = tid >> 5, tc = tid & 31;
+    for (int j = 0; j < k; ++j) {
+        const T s = W[j * ld + j];
+        const T dj = (s > (T)0) ? (T)-1 : (T)1;
+        const T u = (T)1 + fabs(s);
+        if (tid == 0) d[j] = dj;
+        for (int i = j + 1 + ti; i < k; i += 32) {
+            const T li = -dj * W[i * ld + j] / u;
+            for (int cc = j + 1 + tc; cc < k; cc += 32) W[i * ld + cc] -= li * W[j * ld + cc];
+        }
+        __syncthreads();
+    }
+}
+template <typename T>
+__global__ __launch_bounds__(256) void k_scale_cols_rows(Mat<T> q, Mat<T> r, const T *d) {
+    // q(:, j) *= d_j ; r(j, :) *= d_j
+    const int64_t tq = q.rows * q.cols, tr = r.rows * r.cols;
+    for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < tq + tr; e += (int64_t)gridDim.x * blockDim.x) {
+        if (e < tq) {
+            int64_t j = e / q.rows, i = e - j * q.rows;
+            if (d[j] < (T)0) q.at(i, j) = -q.at(i, j);
+        } else {
+            int64_t f = e - tq;
+            int64_t i = f / r.cols, p = f - i * r.cols;
+            if (d[i] < (T)0) r.at(i, p) = -r.at(i, p);
+        }
+    }
+}
+
+template <typename T>
+void householder_sign_fix(rc_context *c, Mat<T> q, Mat<T> r) {
+    const int64_t k = q.cols;
+    if (k == 0) return;
+    RC_REQUIRE(q.rows >= k, RC_INVALID_ARGUMENT, "sign fix: q must be tall");
+    const size_t lds = (size_t)k * (k | 1) * sizeof(T);
+    RC_REQUIRE(lds <= 160 * 1024 - 1024, RC_INVALID_ARGUMENT, "sign fix: k = %lld does not fit LDS", (long long)k);
+    ProfScope ps(c, "op:householder_sign_fix k=%lld", (long long)k);
+    ArenaMark mark(c);
+    T *d = c->alloc<T>((size_t)k);
+    auto kern = k_householder_signs<T>;
+    static bool attr_set[64] = {};
+    if (!attr_set[c->device & 63]) {
+        RC_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024));
+        attr_set[c->device & 63] = true;
+    }
+    hipLaunchKernelGGL(kern, dim3(1), dim3(1024), lds, c->stream, q, d);
+    const int64_t total = q.rows * q.cols + r.rows * r.cols;
+    hipLaunchKernelGGL(k_scale_cols_rows<T>, dim3((unsigned)std::min<int64_t>(cdiv(total, 256), 4096)), dim3(256), 0, c->stream, q, r, d);
+}
+
+// Pivoted (or plain) QR of the tall-skinny y through CholeskyQR2 + small QRCP + sign fix.
+//   q: m x k column-major (may be empty), r: k x n (may be empty), ind: n
+template <typename T>
+void qrcp_tall_fast(rc_context *c, Mat<T> y, int64_t k, bool pivot, Mat<T> q, Mat<T> r, int64_t *ind, int *flag) {
+    const int64_t m = y.rows, n = y.cols;
+    ProfScope ps(c, "op:qrcp_tall_fast %lldx%lld k=%lld pivot=%d", (long long)m, (long long)n, (long long)k, pivot ? 1 : 0);
+    ArenaMark mark(c);
+    Mat<T> q1 = rowmajor(c->alloc<T>((size_t)m * n), m, n, n);
+    Mat<T> r1 = colmajor(c->alloc<T>((size_t)n * n), n, n, n);
+    tsqr_cholqr2<T>(c, y, q1, r1, flag);
+    Mat<T> q2 = colmajor(c->alloc<T>((size_t)n * k), n, k, n);
+    Mat<T> rr = r.empty() ? rowmajor(c->alloc<T>((size_t)k * n), k, n, n) : r;
+    qrcp_small<T>(c, r1, k, pivot, ind, rr, q2);
+    Mat<T> qq = q.empty() ? rowmajor(c->alloc<T>((size_t)m * k), m, k, k) : q;
+    gemm<T>(c, 1, q1, q2, 0, qq);
+    householder_sign_fix<T>(c, qq, rr);
+}
+
+#define RC_INST(T)                                                                                               \
+    template bool tsqr_supported<T>(int64_t, int64_t);                                                           \
+    template void tsqr_cholqr2<T>(rc_context *, Mat<T>, Mat<T>, Mat<T>, int *);                                  \
+    template void qrcp_small<T>(rc_context *, Mat<T>, int64_t, bool, int64_t *, Mat<T>, Mat<T>);                 \
+    template void householder_sign_fix<T>(rc_context *, Mat<T>, Mat<T>);                                         \
+    template void qrcp_tall_fast<T>(rc_context *, Mat<T>, int64_t, bool, Mat<T>, Mat<T>, int64_t *, int *);
+RC_INST(double)
+RC_INST(float)
+#undef RC_INST
+
+}  // namespace rc

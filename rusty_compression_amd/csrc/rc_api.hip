@@ -81,8 +81,18 @@ void rc_context::prof_resolve() {
     prof_pending.clear();
 }
 
+int *rc_context::health_word() {
+    if (!health) {
+        RC_HIP(hipMalloc(reinterpret_cast<void **>(&health), sizeof(int)));
+        RC_HIP(hipMemset(health, 0, sizeof(int)));
+    }
+    return health;
+}
+
 void rc_context::release_all() {
     (void)hipStreamSynchronize(stream);
+    if (health) (void)hipFree(health);
+    health = nullptr;
     prof_resolve();
     for (hipEvent_t e : prof_free) (void)hipEventDestroy(e);
     prof_free.clear();
@@ -163,12 +173,38 @@ void check_view(const rc_matrix &m, const char *name, bool allow_null = false) {
 // compositions (templated on the scalar type)
 // ===========================================================================
 
+__global__ void k_or_flag(int *dst, const int *src) {
+    if (threadIdx.x == 0 && blockIdx.x == 0 && *src) atomicOr(dst, *src);
+}
+
+// Runs `fast(flag)` (which ORs failure bits into the device int `flag`) and reports whether
+// its result may be kept.  Outside graph capture the flag is read back (one small sync) so
+// the caller can fall back; during capture the bits go to the context's health word instead.
+template <typename F>
+bool run_certified(rc_context *c, F &&fast) {
+    int *flag = c->alloc<int>(1);
+    RC_HIP(hipMemsetAsync(flag, 0, sizeof(int), c->stream));
+    fast(flag);
+    if (c->capturing) {
+        hipLaunchKernelGGL(k_or_flag, dim3(1), dim3(64), 0, c->stream, c->health_word(), flag);
+        return true;
+    }
+    int h = 0;
+    read_back(c, flag, &h, 1);
+    return h == 0;
+}
+
 // Pivoted QR of the column-major working matrix w (destroyed).
 //   q: m x k (may be empty to skip), r: k x n (may be empty), ind: n, k <= min(m, n)
+// Tall-skinny inputs take the CholeskyQR2 + LDS-QRCP + sign-fix path (kernels_tsqr.hip) and
+// fall back to the Householder chain when its certificate fails (cond(w)^2 eps not << 1).
 template <typename T>
 void qrcp_core(rc_context *c, Mat<T> w, int64_t k, bool pivot, Mat<T> q, Mat<T> r, int64_t *ind) {
     const int64_t n = w.cols;
     ArenaMark mark(c);
+    if (c->opt_tsqr && k >= 1 && tsqr_supported<T>(w.rows, n)) {
+        if (run_certified(c, [&](int *flag) { qrcp_tall_fast<T>(c, w, k, pivot, q, r, ind, flag); })) return;
+    }
     T *tau = c->alloc<T>((size_t)std::max<int64_t>(k, 1));
     T *vn = c->alloc<T>((size_t)std::max<int64_t>(2 * n, 1));
     geqp3_inplace(c, w, k, pivot, ind, tau, vn);
@@ -205,15 +241,21 @@ template <typename T>
 void svd_core(rc_context *c, Mat<T> wt, bool transposed, Mat<T> u, T *s, Mat<T> vt) {
     const int64_t M = wt.rows, r = wt.cols;
     ArenaMark mark(c);
-    int64_t *jp = c->alloc<int64_t>((size_t)std::max<int64_t>(r, 1));
-    T *tau = c->alloc<T>((size_t)std::max<int64_t>(r, 1));
-    T *vn = c->alloc<T>((size_t)std::max<int64_t>(2 * r, 1));
-    geqp3_inplace(c, wt, r, false, jp, tau, vn);
     Mat<T> core = tmp_colmajor<T>(c, r, r);
-    // tall: core = R ; wide: core = L = R^T  (a = L Q_w^T)
-    extract_r(c, wt, jp, transposed ? core.t() : core);
     Mat<T> qw = tmp_colmajor<T>(c, M, r);
-    form_q(c, wt, jp, tau, r, qw);
+    bool done = false;
+    if (c->opt_tsqr && tsqr_supported<T>(M, r)) {
+        // tall: core = R ; wide: core = L = R^T  (a = L Q_w^T)
+        done = run_certified(c, [&](int *flag) { tsqr_cholqr2<T>(c, wt, qw, transposed ? core.t() : core, flag); });
+    }
+    if (!done) {
+        int64_t *jp = c->alloc<int64_t>((size_t)std::max<int64_t>(r, 1));
+        T *tau = c->alloc<T>((size_t)std::max<int64_t>(r, 1));
+        T *vn = c->alloc<T>((size_t)std::max<int64_t>(2 * r, 1));
+        geqp3_inplace(c, wt, r, false, jp, tau, vn);
+        extract_r(c, wt, jp, transposed ? core.t() : core);
+        form_q(c, wt, jp, tau, r, qw);
+    }
     Mat<T> vwork = tmp_colmajor<T>(c, r, r), uc = tmp_colmajor<T>(c, r, r), vc = tmp_colmajor<T>(c, r, r);
     jacobi_svd(c, core, vwork, uc, s, vc);
     if (!transposed) {
@@ -586,6 +628,10 @@ rc_status rc_create(rc_context **ctx, int32_t device, void *hip_stream) {
     rc_context *c = new rc_context();
     c->device = device;
     c->stream = static_cast<hipStream_t>(hip_stream);
+    {
+        DeviceGuard dg(device);
+        try { (void)c->health_word(); } catch (const Error &) { delete c; return RC_RUNTIME_ERROR; }
+    }
     *ctx = c;
     return RC_OK;
 }
@@ -696,6 +742,28 @@ rc_status rc_graph_destroy(rc_context *ctx, void *graph_exec) {
     DeviceGuard dg(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
     (void)hipGraphExecDestroy(static_cast<hipGraphExec_t>(graph_exec));
+    return RC_OK;
+}
+
+// ---- options / health -----------------------------------------------------------
+rc_status rc_set_option(rc_context *ctx, int32_t option, int64_t value) {
+    if (!ctx) return RC_INVALID_ARGUMENT;
+    switch (option) {
+        case RC_OPT_TALL_SKINNY_FAST_PATH: ctx->opt_tsqr = value != 0; return RC_OK;
+        default: ctx->last_error = "unknown option"; return RC_INVALID_ARGUMENT;
+    }
+}
+rc_status rc_get_health(rc_context *ctx, int32_t *word) {
+    if (!ctx || !word) return RC_INVALID_ARGUMENT;
+    DeviceGuard dg(ctx->device);
+    *word = 0;
+    if (!ctx->health) return RC_OK;
+    hipError_t e = hipStreamSynchronize(ctx->stream);
+    int h = 0;
+    if (e == hipSuccess) e = hipMemcpy(&h, ctx->health, sizeof(int), hipMemcpyDeviceToHost);
+    if (e == hipSuccess) e = hipMemset(ctx->health, 0, sizeof(int));
+    if (e != hipSuccess) { ctx->last_error = hipGetErrorString(e); return RC_RUNTIME_ERROR; }
+    *word = h;
     return RC_OK;
 }
 

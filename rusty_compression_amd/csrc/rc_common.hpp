@@ -94,6 +94,14 @@ struct rc_context {
     void *pinned = nullptr;             // small pinned host buffer for scalar read-backs
     size_t pinned_size = 0;
 
+    // Tall-skinny factorizations: 1 = CholeskyQR2 fast path with certificate + Householder
+    // fallback (default), 0 = always the Householder chain.  `health` is a device word the
+    // fast path ORs its failure bits into; outside graph capture it is read back (one small
+    // synchronisation) and the call falls back, during capture it is left for rc_get_health.
+    int opt_tsqr = 1;
+    int *health = nullptr;
+    int *health_word();
+
     // hipGraph capture state and the event-based stage/kernel timers (rc_profile_*)
     bool capturing = false;
     bool prof_on = false;
@@ -182,6 +190,12 @@ template <typename T> void extract_r(rc_context *c, Mat<T> w, const int64_t *jpv
 template <typename T> void form_q(rc_context *c, Mat<T> w, const int64_t *jpvt, const T *tau, int64_t k, Mat<T> qw);
 // solve T X = B in place; t: k x k upper triangular view (any strides), b: k x nrhs view
 template <typename T> void trsm_upper(rc_context *c, Mat<T> t, Mat<T> b);
+// tall-skinny fast path (kernels_tsqr.hip): CholeskyQR2 + LDS-resident QRCP + Householder sign fix
+template <typename T> bool tsqr_supported(int64_t m, int64_t n);
+template <typename T> void tsqr_cholqr2(rc_context *c, Mat<T> y, Mat<T> q, Mat<T> r, int *flag);
+template <typename T> void qrcp_small(rc_context *c, Mat<T> rin, int64_t kmax, bool pivot, int64_t *jpvt, Mat<T> rout, Mat<T> q2);
+template <typename T> void householder_sign_fix(rc_context *c, Mat<T> q, Mat<T> r);
+template <typename T> void qrcp_tall_fast(rc_context *c, Mat<T> y, int64_t k, bool pivot, Mat<T> q, Mat<T> r, int64_t *ind, int *flag);
 // one-sided Jacobi SVD of the square column-major n x n matrix g (destroyed):
 //   uc (n x n col-major) = left vectors, s (n) descending, vc (n x n col-major) = right vectors
 template <typename T> void jacobi_svd(rc_context *c, Mat<T> g, Mat<T> vwork, Mat<T> uc, T *s, Mat<T> vc);

@@ -407,3 +407,98 @@ def test_random_test_matrix_generators():
     assert np.abs(u.T @ u - np.eye(30)).max() <= 1e-12
     w = npy(rc.random_orthogonal_matrix((30, 90), rc.Rng(2)))
     assert np.abs(w @ w.T - np.eye(30)).max() <= 1e-12
+
+
+# ---------------------------------------------------------------- tall-skinny fast path (CholeskyQR2 + LDS QRCP + sign fix)
+def _with_fast_path(on, fn):
+    from rusty_compression_amd import _lib
+
+    ctx = _lib.default_context()
+    ctx.set_option(_lib.RC_OPT_TALL_SKINNY_FAST_PATH, 1 if on else 0)
+    try:
+        return fn()
+    finally:
+        ctx.set_option(_lib.RC_OPT_TALL_SKINNY_FAST_PATH, 1)
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+@pytest.mark.parametrize("shape,smin", [((4096, 69), 1e-3), ((8192, 133), 1e-2), ((2048, 33), 1e-3), ((1500, 17), 1e-1)])
+def test_fast_path_reproduces_lapack_pivots_signs_and_factors(dtype, shape, smin):
+    rng = np.random.default_rng(shape[1])
+    if dtype == np.float32:
+        smin = max(smin, 3e-2)  # keep cond^2 * eps_f32 << 1 so the certificate holds and the fast path is what is tested
+    a = o.random_approximate_low_rank_matrix(shape, 1.0, smin, rng, dtype)
+    q, r, ind = o.pivoted_qr(a)
+    f64 = dtype == np.float64
+    for fast in (True, False):
+        gq, gr, gi = _with_fast_path(fast, lambda: tuple(npy(t) for t in rc.pivoted_qr(a)))
+        ns = agreed_pivot_prefix(gi, gr, ind, r, dtype)
+        assert is_permutation(gi, shape[1])
+        if f64:
+            assert ns == shape[1], (fast, ns)
+            assert rel(gr, r) <= 1e-10, (fast, rel(gr, r))          # same signs as ?geqp3
+            assert rel(gq, q) <= 1e-9, (fast, rel(gq, q))            # same signs as ?orgqr
+        else:
+            assert rel(gr[:ns, :ns], r[:ns, :ns]) <= 1e-4
+        assert rel(gq @ gr, a[:, gi]) <= (1e-13 if f64 else 5e-6)
+        assert np.abs(gq.T @ gq - np.eye(shape[1])).max() <= (1e-13 if f64 else 1e-5)
+    # truncated + LQ orientation through the same path
+    gq, gr, gi = (npy(t) for t in rc.pivoted_qr(a, rank=shape[1] // 2))
+    kk = shape[1] // 2
+    if f64:
+        assert np.array_equal(gi[:kk], ind[:kk]) and rel(gq, q[:, :kk]) <= 1e-9
+    l, ql, indl = (npy(t) for t in rc.pivoted_lq(a.T.copy()))
+    if f64:
+        assert np.array_equal(indl, ind) and rel(l, r.T) <= 1e-10 and rel(ql, q.T) <= 1e-9
+
+
+def test_fast_path_falls_back_when_its_certificate_fails():
+    rng = np.random.default_rng(77)
+    # cond 1e10: cond^2 eps >> 1, CholeskyQR2 cannot work; the call must still return LAPACK-quality factors
+    a = o.random_approximate_low_rank_matrix((3000, 40), 1.0, 1e-10, rng)
+    q, r, ind = o.pivoted_qr(a)
+    gq, gr, gi = (npy(t) for t in rc.pivoted_qr(a))
+    assert np.array_equal(gi, ind) and rel(gr, r) <= 1e-10
+    assert np.abs(gq.T @ gq - np.eye(40)).max() <= 1e-13 and rel(gq @ gr, a[:, gi]) <= 1e-13
+    u, s, vt = (npy(t) for t in rc.compute_svd(a))
+    assert np.abs(s - o.compute_svd(a)[1]).max() / s[0] <= 1e-12
+    assert np.abs(u.T @ u - np.eye(40)).max() <= 1e-12
+    # rank-deficient sketch: exactly singular Gram matrix
+    b = rng.standard_normal((2048, 10)) @ rng.standard_normal((10, 24))
+    gq, gr, gi = (npy(t) for t in rc.pivoted_qr(b))
+    assert rel(gq @ gr, b[:, gi]) <= 1e-12 and np.abs(gq.T @ gq - np.eye(24)).max() <= 1e-12
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_svd_of_tall_and_wide_matrices_through_both_paths(dtype):
+    rng = np.random.default_rng(5)
+    tol = TOL[np.dtype(dtype)]
+    for shape in ((4096, 96), (128, 8192), (2048, 128)):
+        a = o.random_approximate_low_rank_matrix(shape, 1.0, 1e-2, rng, dtype)
+        s_ref = o.compute_svd(a)[1]
+        for fast in (True, False):
+            u, s, vt = _with_fast_path(fast, lambda: tuple(npy(t) for t in rc.compute_svd(a)))
+            assert np.abs(s - s_ref).max() / s_ref[0] <= tol["sval"] * 4
+            assert rel(u @ np.diag(s) @ vt, a) <= tol["recon"] * 4
+            r_ = min(shape)
+            assert np.abs(u.T @ u - np.eye(r_)).max() <= (1e-12 if dtype == np.float64 else 1e-4)
+            assert np.abs(vt @ vt.T - np.eye(r_)).max() <= (1e-12 if dtype == np.float64 else 1e-4)
+
+
+def test_headline_size_sketch_matches_the_oracle():
+    """cfg2 / cfg3 shapes with device-generated inputs; oracle in GEMM form on the same bits."""
+    for (n, k) in ((4096, 64), (8192, 128)):
+        a = rc.random_gaussian((n, n), rc.Rng(n))
+        om = rc.random_gaussian((n, k + 5), rc.Rng(1))
+        q = rc.sample_range_by_rank(a, k, 5, om)
+        an, omn = npy(a), npy(om)
+        oq = o.sample_range_by_rank(an, k, 5, lambda s: omn)
+        assert rel(npy(q), oq) <= 1e-10
+        svd = rc.SVD.compute_from_range_estimate(q, a)
+        osv = o.SVD.compute_from_range_estimate(oq, an)
+        assert np.abs(npy(svd.s) - osv.s).max() / osv.s[0] <= 1e-12
+        assert rel(npy(svd.to_mat()), osv.to_mat()) <= 1e-10
+        qr = rc.QR.compute_from_range_estimate(q, a)
+        oqr = o.QR.compute_from_range_estimate(oq, an)
+        assert np.array_equal(npy(qr.ind)[:k], oqr.ind[:k])
+        assert rel(npy(qr.r), oqr.r) <= 1e-10

@@ -1,27 +1,40 @@
 #!/bin/bash
-# One GPU-box session: parity tests, developer checks, bench variants, rocprof kernel trace.
-# Every step writes under gpurun_out/ ; steps are joined so a hang stops the chain.
+# One GPU-box session: parity tests, bench variants, rocprof kernel trace.
+# Every step writes under gpurun_out/ ; a failing/hanging GPU step stops the chain.
 set -o pipefail
 mkdir -p gpurun_out
 export TMPDIR=/tmp
+R=$GRAFT_REPO_ROOT
 echo "== pytest -m gpu" | tee gpurun_out/progress.log
-timeout -k 10 600 python -m pytest tests -m gpu -q -x --timeout=300 > gpurun_out/pytest_gpu.log 2>&1
-echo "pytest exit=$?" | tee -a gpurun_out/progress.log
-tail -5 gpurun_out/pytest_gpu.log
-echo "== dev checks" | tee -a gpurun_out/progress.log
-timeout -k 10 400 python tools/dev_gpu_check.py id sampling big > gpurun_out/dev2.log 2>&1
-echo "dev exit=$?" | tee -a gpurun_out/progress.log
-echo "== bench streams=1 eager" | tee -a gpurun_out/progress.log
-timeout -k 10 300 python bench.py --steps 8 --warmup 2 --streams 1 --no-graph --no-cpu-baseline > gpurun_out/bench_s1_eager.json 2> gpurun_out/bench_s1_eager.err
-echo "exit=$?" | tee -a gpurun_out/progress.log
+timeout -k 10 900 python -m pytest tests -m gpu -q --timeout=600 > gpurun_out/pytest_gpu.log 2>&1
+rc=$?; echo "pytest exit=$rc" | tee -a gpurun_out/progress.log
+tail -15 gpurun_out/pytest_gpu.log
+if [ $rc -ge 124 ]; then exit 1; fi
 echo "== bench streams=1 graph" | tee -a gpurun_out/progress.log
-timeout -k 10 300 python bench.py --steps 8 --warmup 2 --streams 1 --no-cpu-baseline > gpurun_out/bench_s1_graph.json 2> gpurun_out/bench_s1_graph.err
-echo "exit=$?" | tee -a gpurun_out/progress.log
-echo "== bench default (streams=4 graph, cpu baseline)" | tee -a gpurun_out/progress.log
-timeout -k 10 500 python bench.py > gpurun_out/bench_default.json 2> gpurun_out/bench_default.err
-echo "exit=$?" | tee -a gpurun_out/progress.log
-cat gpurun_out/bench_default.json
+timeout -k 10 300 python bench.py --steps 8 --warmup 2 --streams 1 --no-cpu-baseline > gpurun_out/bench_s1_graph.json 2> gpurun_out/bench_s1_graph.err || { echo "bench s1 failed"; tail -5 gpurun_out/bench_s1_graph.err; exit 1; }
+python - <<'PY'
+import json
+d=json.load(open('gpurun_out/bench_s1_graph.json'))
+print('s1:', d['value'], 'c/s', d['ms_per_step'], 'ms/step')
+for k,v in d['stage_ms_single_stream_eager'].items(): print('   ', k, v)
+print('   roofline', d['roofline']['achieved'], d['roofline']['frac'])
+PY
+echo "== bench default" | tee -a gpurun_out/progress.log
+timeout -k 10 500 python bench.py ${BENCH_ARGS:-} > gpurun_out/bench_default.json 2> gpurun_out/bench_default.err || { echo "bench default failed"; tail -5 gpurun_out/bench_default.err; exit 1; }
+python -c "
+import json; d=json.load(open('gpurun_out/bench_default.json')); print('default:', d['value'], 'c/s', d['ms_per_step'], 'ms/step', 'gemm frac', d['roofline']['frac'], 'cpu', d['cpu_baseline'])"
+echo "== bench streams=8" | tee -a gpurun_out/progress.log
+timeout -k 10 300 python bench.py --streams 8 --no-cpu-baseline > gpurun_out/bench_s8.json 2> gpurun_out/bench_s8.err
+python -c "
+import json; d=json.load(open('gpurun_out/bench_s8.json')); print('s8:', d['value'], 'c/s', d['ms_per_step'], 'ms/step')"
 echo "== rocprofv3 kernel trace of bench" | tee -a gpurun_out/progress.log
-cd /tmp && timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/prof_bench -- python3 $GRAFT_REPO_ROOT/bench.py --steps 8 --warmup 2 --no-cpu-baseline > $GRAFT_REPO_ROOT/gpurun_out/rocprof_bench.log 2>&1
-echo "rocprof exit=$?" | tee -a $GRAFT_REPO_ROOT/gpurun_out/progress.log
-cd $GRAFT_REPO_ROOT && find gpurun_out/prof_bench -name "*stats*" | head
+rm -rf gpurun_out/prof_bench
+cd /tmp && timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_bench -- python3 $R/bench.py --steps 8 --warmup 2 --no-cpu-baseline > $R/gpurun_out/rocprof_bench.log 2>&1
+echo "rocprof exit=$?" | tee -a $R/gpurun_out/progress.log
+cd $R && python - <<'PY'
+import csv,glob
+f=glob.glob('gpurun_out/prof_bench/*/*kernel_stats.csv')[0]
+rows=list(csv.DictReader(open(f)))
+for r in rows[:16]:
+    print(r['Name'][:80].ljust(80), r['Calls'].rjust(6), ('%.1f'%(float(r['AverageNs'])/1000)).rjust(9),'us', r['Percentage'])
+PY
