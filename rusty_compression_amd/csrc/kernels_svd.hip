@@ -24,6 +24,9 @@
 //  * k_jacobi_global: fallback for cores that do not fit LDS (n <= 1024),
 //    everything in L2-resident global memory.
 #include "rc_common.hpp"
+#include "rc_device.hpp"
+
+#include <cstdlib>
 
 namespace rc {
 
@@ -31,34 +34,7 @@ template <typename T> struct JEps;
 template <> struct JEps<double> { static __device__ inline double eps() { return 1.1102230246251565e-16; } };
 template <> struct JEps<float> { static __device__ inline float eps() { return 5.9604644775390625e-08f; } };
 
-// ---- sum over the 16 lanes of a DPP row; every lane gets the total -------------
-__device__ inline float dpp_row_sum(float v) {
-    int x;
-    x = __builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xF, 0xF, true);  // quad_perm [1,0,3,2]
-    v += __int_as_float(x);
-    x = __builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xF, 0xF, true);  // quad_perm [2,3,0,1]
-    v += __int_as_float(x);
-    x = __builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x141, 0xF, 0xF, true);  // row_half_mirror
-    v += __int_as_float(x);
-    x = __builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x140, 0xF, 0xF, true);  // row_mirror
-    v += __int_as_float(x);
-    return v;
-}
-template <int CTRL>
-__device__ inline double dpp_mov64(double v) {
-    long long b = __double_as_longlong(v);
-    int lo = (int)(b & 0xffffffffLL), hi = (int)(b >> 32);
-    int rlo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xF, 0xF, true);
-    int rhi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xF, 0xF, true);
-    return __longlong_as_double(((long long)rhi << 32) | (unsigned int)rlo);
-}
-__device__ inline double dpp_row_sum(double v) {
-    v += dpp_mov64<0xB1>(v);   // quad_perm [1,0,3,2]
-    v += dpp_mov64<0x4E>(v);   // quad_perm [2,3,0,1]
-    v += dpp_mov64<0x141>(v);  // row_half_mirror
-    v += dpp_mov64<0x140>(v);  // row_mirror
-    return v;
-}
+template <typename T> __device__ inline T dpp_row_sum(T v) { return group_sum_dpp<16>(v); }
 
 // Workgroup barrier that orders LDS traffic only.  __syncthreads() also waits for
 // outstanding GLOBAL stores (vmcnt(0)); the rotation-log stores are write-only and
@@ -76,15 +52,18 @@ __device__ inline void rr_pair(int N, int r, int pi, int &p, int &q) {
 template <typename T> struct Rot { T c, s; };
 
 // ---------------------------------------------------------------------------
-// LDS-resident one-sided Jacobi.  NE = ceil(n / 16) rows per lane (compile time).
+// LDS-resident one-sided Jacobi.  LPP lanes own one column pair and keep NE = ceil(n / LPP)
+// rows of both columns in registers; with LPP = 4 a 128 x 128 core needs only 4 waves
+// (one per SIMD), which minimises the per-pair overhead (reductions + rotation
+// parameters are paid per wave instruction, not per element).
 //   g      : n x n column-major input (global), destroyed
 //   log    : [max_sweeps][N-1][N/2] rotations (c = 1, s = 0 where none)
 //   sweeps : number of sweeps performed (device scalar out)
 //   uc, s  : left singular vectors / singular values, sorted descending
 //   order  : order[j] = sorted position of original column j (for the V replay)
 // ---------------------------------------------------------------------------
-template <typename T, int NE>
-__global__ __launch_bounds__(1024) void k_jacobi_lds(Mat<T> g, Rot<T> *log, int *sweeps_out, Mat<T> uc, T *s, int *order_out, int max_sweeps) {
+template <typename T, int LPP, int NE>
+__global__ __launch_bounds__(LPP == 16 ? 1024 : 512) void k_jacobi_lds(Mat<T> g, Rot<T> *log, int *sweeps_out, Mat<T> uc, T *s, int *order_out, int max_sweeps) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     const int n = (int)g.rows;
     const int ld = n | 1;  // odd pitch: column starts spread over all banks
@@ -93,13 +72,14 @@ __global__ __launch_bounds__(1024) void k_jacobi_lds(Mat<T> g, Rot<T> *log, int 
     int *order = reinterpret_cast<int *>(sig + n);
     volatile int *sh_rot_p = order + n;  // all LDS in the one dynamic array (keeps its base aligned)
 #define sh_rot (*sh_rot_p)
-    const int tid = threadIdx.x;
-    const int l16 = tid & 15, grp = tid >> 4;  // 64 groups (DPP rows) of 16 lanes
+    const int tid = threadIdx.x, nthr = blockDim.x;
+    const int ll = tid % LPP, grp = tid / LPP, ngrp = nthr / LPP;
     const int N = (n + 1) & ~1;
     const int npairs = N / 2;
     const T tol = sqrt((T)n) * JEps<T>::eps();
+    const T tol2 = tol * tol;
 
-    for (int e = tid; e < n * n; e += 1024) {
+    for (int e = tid; e < n * n; e += nthr) {
         int i = e % n, j = e / n;
         G[j * ld + i] = g.p[(int64_t)j * g.cs + i];
     }
@@ -110,7 +90,7 @@ __global__ __launch_bounds__(1024) void k_jacobi_lds(Mat<T> g, Rot<T> *log, int 
         if (tid == 0) sh_rot = 0;
         __syncthreads();
         for (int r = 0; r < N - 1; ++r) {
-            for (int pi = grp; pi < npairs; pi += 64) {
+            for (int pi = grp; pi < npairs; pi += ngrp) {
                 int p, q;
                 rr_pair(N, r, pi, p, q);
                 Rot<T> rot{(T)1, (T)0};
@@ -120,29 +100,34 @@ __global__ __launch_bounds__(1024) void k_jacobi_lds(Mat<T> g, Rot<T> *log, int 
                     T app = 0, aqq = 0, apq = 0;
 #pragma unroll
                     for (int e = 0; e < NE; ++e) {
-                        int i = l16 + 16 * e;
+                        int i = ll + LPP * e;
                         a[e] = (i < n) ? gp[i] : (T)0;
                         b[e] = (i < n) ? gq[i] : (T)0;
-                        app += a[e] * a[e]; aqq += b[e] * b[e]; apq += a[e] * b[e];
+                        app = fma(a[e], a[e], app); aqq = fma(b[e], b[e], aqq); apq = fma(a[e], b[e], apq);
                     }
-                    app = dpp_row_sum(app); aqq = dpp_row_sum(aqq); apq = dpp_row_sum(apq);
-                    if (apq != (T)0 && fabs(apq) > tol * sqrt(app) * sqrt(aqq)) {  // uniform over the 16 lanes
-                        const T zeta = (aqq - app) / ((T)2 * apq);
-                        const T t = copysign((T)1, zeta) / (fabs(zeta) + sqrt((T)1 + zeta * zeta));
-                        rot.c = (T)1 / sqrt((T)1 + t * t);
+                    app = group_sum_dpp<LPP>(app); aqq = group_sum_dpp<LPP>(aqq); apq = group_sum_dpp<LPP>(apq);
+                    // rotate iff |apq| > tol * sqrt(app * aqq)   (uniform over the LPP lanes)
+                    if (apq * apq > tol2 * app * aqq) {
+                        const T zeta = (aqq - app) * fast_rcp((T)2 * apq);
+                        const T az = fabs(zeta);
+                        // t = sign(zeta) / (|zeta| + sqrt(1 + zeta^2)); a huge |zeta| (tiny angle) is safe: t -> 0
+                        const T w = (T)1 + az * az;
+                        const T root = (az < (T)1e18) ? w * fast_rsqrt(w) : az;
+                        const T t = copysign(fast_rcp(az + root), zeta);
+                        rot.c = fast_rsqrt((T)1 + t * t);
                         rot.s = rot.c * t;
 #pragma unroll
                         for (int e = 0; e < NE; ++e) {
-                            int i = l16 + 16 * e;
+                            int i = ll + LPP * e;
                             if (i < n) {
                                 gp[i] = rot.c * a[e] - rot.s * b[e];
                                 gq[i] = rot.s * a[e] + rot.c * b[e];
                             }
                         }
-                        if (l16 == 0) sh_rot = 1;
+                        if (ll == 0) sh_rot = 1;
                     }
                 }
-                if (l16 == 0) log[((size_t)sweep * (N - 1) + r) * npairs + pi] = rot;
+                if (ll == 0) log[((size_t)sweep * (N - 1) + r) * npairs + pi] = rot;
             }
             lds_barrier();  // pairs of one round are disjoint; the next round re-pairs the columns
         }
@@ -153,15 +138,15 @@ __global__ __launch_bounds__(1024) void k_jacobi_lds(Mat<T> g, Rot<T> *log, int 
     if (tid == 0) *sweeps_out = sweep;
 
     // singular values = column norms; stable descending rank sort (gesdd order)
-    for (int j = grp; j < n; j += 64) {
+    for (int j = grp; j < n; j += ngrp) {
         const T *gj = G + j * ld;
         T acc = 0;
-        for (int i = l16; i < n; i += 16) acc += gj[i] * gj[i];
-        acc = dpp_row_sum(acc);
-        if (l16 == 0) sig[j] = sqrt(acc);
+        for (int i = ll; i < n; i += LPP) acc += gj[i] * gj[i];
+        acc = group_sum_dpp<LPP>(acc);
+        if (ll == 0) sig[j] = sqrt(acc);
     }
     __syncthreads();
-    for (int i = tid; i < n; i += 1024) {
+    for (int i = tid; i < n; i += nthr) {
         int rank = 0;
         const T si = sig[i];
         for (int j = 0; j < n; ++j) rank += (sig[j] > si || (sig[j] == si && j < i)) ? 1 : 0;
@@ -170,12 +155,12 @@ __global__ __launch_bounds__(1024) void k_jacobi_lds(Mat<T> g, Rot<T> *log, int 
         s[rank] = si;
     }
     __syncthreads();
-    for (int j = grp; j < n; j += 64) {
+    for (int j = grp; j < n; j += ngrp) {
         const int dst = order[j];
         const T sj = sig[j];
         const T inv = sj > (T)0 ? (T)1 / sj : (T)0;
         const T *gj = G + j * ld;
-        for (int i = l16; i < n; i += 16) uc.at(i, dst) = gj[i] * inv;
+        for (int i = ll; i < n; i += LPP) uc.at(i, dst) = gj[i] * inv;
     }
 #undef sh_rot
 }
@@ -300,22 +285,44 @@ __global__ __launch_bounds__(1024) void k_jacobi_global(Mat<T> g, Mat<T> v, Mat<
     }
 }
 
-template <typename T, int NE>
+template <typename T, int LPP, int NE>
 static void launch_lds(rc_context *c, Mat<T> g, Mat<T> uc, T *s, Mat<T> vc, size_t lds, int max_sweeps) {
     const int n = (int)g.rows, N = (n + 1) & ~1;
     ArenaMark mark(c);
     Rot<T> *log = c->alloc<Rot<T>>((size_t)max_sweeps * (N - 1) * (N / 2));
     int *sweeps = c->alloc<int>(1);
     int *order = c->alloc<int>((size_t)n);
-    auto kern = k_jacobi_lds<T, NE>;
+    auto kern = k_jacobi_lds<T, LPP, NE>;
     static bool attr_set[64] = {};
     if (!attr_set[c->device & 63]) {
         RC_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 2048));
         attr_set[c->device & 63] = true;
     }
-    hipLaunchKernelGGL(kern, dim3(1), dim3(1024), lds, c->stream, g, log, sweeps, uc, s, order, max_sweeps);
+    // one LPP-lane group per pair, rounded up to whole waves
+    const int threads = std::min(LPP == 16 ? 1024 : 512, std::max(64, (((N / 2) * LPP + 63) / 64) * 64));
+    hipLaunchKernelGGL(kern, dim3(1), dim3(threads), lds, c->stream, g, log, sweeps, uc, s, order, max_sweeps);
     const size_t lds_v = 4 * (size_t)(n + 1) * sizeof(T);
     hipLaunchKernelGGL(k_jacobi_replay_v<T>, dim3((unsigned)((n + 3) / 4)), dim3(256), lds_v, c->stream, n, log, sweeps, order, vc);
+    if (c->prof_on && !c->capturing) {  // diagnostic: number of sweeps, reported through the profile table
+        int h = 0;
+        (void)hipStreamSynchronize(c->stream);
+        (void)hipMemcpy(&h, sweeps, sizeof(int), hipMemcpyDeviceToHost);
+        char nm[64];
+        snprintf(nm, sizeof(nm), "info:jacobi_sweeps n=%d", n);
+        auto &a = c->prof_acc[nm];
+        a.ms += h;
+        a.calls += 1;
+    }
+}
+
+template <typename T, int LPP>
+static void launch_lds_lpp(rc_context *c, Mat<T> g, Mat<T> uc, T *s, Mat<T> vc, size_t lds, int max_sweeps) {
+    const int n = (int)g.rows;
+    constexpr int U = 32 / LPP;  // rows per lane at n = 32
+    if (n <= 32) launch_lds<T, LPP, U>(c, g, uc, s, vc, lds, max_sweeps);
+    else if (n <= 64) launch_lds<T, LPP, 2 * U>(c, g, uc, s, vc, lds, max_sweeps);
+    else if (n <= 128) launch_lds<T, LPP, 4 * U>(c, g, uc, s, vc, lds, max_sweeps);
+    else launch_lds<T, LPP, 6 * U>(c, g, uc, s, vc, lds, max_sweeps);  // f32 up to n = 192 (the LDS bound is ~200)
 }
 
 template <typename T>
@@ -329,10 +336,10 @@ void jacobi_svd(rc_context *c, Mat<T> g, Mat<T> vwork, Mat<T> uc, T *s, Mat<T> v
     const int max_sweeps = 30;
     const size_t lds = ((size_t)(n | 1) * n + n) * sizeof(T) + (size_t)n * sizeof(int) + 64;
     if (lds <= 160 * 1024 - 2048 - 64 && n <= 192) {
-        if (n <= 32) launch_lds<T, 2>(c, g, uc, s, vc, lds, max_sweeps);
-        else if (n <= 64) launch_lds<T, 4>(c, g, uc, s, vc, lds, max_sweeps);
-        else if (n <= 128) launch_lds<T, 8>(c, g, uc, s, vc, lds, max_sweeps);
-        else launch_lds<T, 12>(c, g, uc, s, vc, lds, max_sweeps);  // f32 up to n = 192 (the LDS bound is ~200)
+        static const int lpp = [] { const char *e = getenv("RC_JACOBI_LPP"); return e ? atoi(e) : 16; }();
+        if (lpp == 4) launch_lds_lpp<T, 4>(c, g, uc, s, vc, lds, max_sweeps);
+        else if (lpp == 8) launch_lds_lpp<T, 8>(c, g, uc, s, vc, lds, max_sweeps);
+        else launch_lds_lpp<T, 16>(c, g, uc, s, vc, lds, max_sweeps);
     } else {
         hipLaunchKernelGGL(k_jacobi_global<T>, dim3(1), dim3(1024), 0, c->stream, g, vwork, uc, s, vc, 60);
     }

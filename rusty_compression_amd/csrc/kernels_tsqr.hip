@@ -21,6 +21,7 @@
 // Replaces: ?geqp3 + ?orgqr on sketches (/root/reference/src/pivoted_qr.rs:81-183 as called
 // from src/random_sampling.rs:114) and the QR/LQ reduction inside ?gesdd (src/compute_svd.rs:19).
 #include "rc_common.hpp"
+#include "rc_device.hpp"
 
 namespace rc {
 
@@ -54,26 +55,37 @@ __device__ inline T row_sum16(T v) {  // sum over an aligned group of 16 lanes
 //   flag bit 0: non-positive pivot (G not numerically SPD)
 //   flag bit 1: check_identity && max|G - I| > ident_tol  (first pass left Q1 too far from orthonormal)
 // ---------------------------------------------------------------------------
-template <typename T>
+template <typename T, int NT>
 __global__ __launch_bounds__(1024) void k_chol_inv(Mat<T> g, Mat<T> r_out, Mat<T> rinv_out, int check_identity, T ident_tol, int *flag) {
+    // Register-tiled right-looking Cholesky: thread (ti, tc) of the 32 x 32 thread grid owns
+    // the entries (ti + 32 a, tc + 32 b), a, b < NT, in registers; per step only pivot row j
+    // goes through LDS (double buffered: ONE barrier per step).
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     const int n = (int)g.rows;
     const int ld = n | 1;
-    T *A = reinterpret_cast<T *>(smem_raw);  // A[i * ld + c]
-    T *svec = A + (size_t)n * ld;
-    __shared__ T red[16];
+    T *A = reinterpret_cast<T *>(smem_raw);  // A[i * ld + c], used by the inversion phase
+    T *svec = A + (size_t)n * ld;            // n
+    T *rowbuf = svec + n;                    // 2 * n
+    T *red = rowbuf + 2 * n;                 // 16
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int ti = tid >> 5, tc = tid & 31;
 
+    T reg[NT][NT];
     T dev = 0;
-    for (int e = tid; e < n * n; e += 1024) {
-        int i = e / n, c = e % n;
-        T v = g.at(i, c);
-        A[i * ld + c] = v;
-        dev = max(dev, fabs(v - ((i == c) ? (T)1 : (T)0)));
-    }
-    if (check_identity) {
 #pragma unroll
-        for (int off = 32; off > 0; off >>= 1) dev = max(dev, __shfl_xor(dev, off, 64));
+    for (int a = 0; a < NT; ++a)
+#pragma unroll
+        for (int b = 0; b < NT; ++b) {
+            const int i = ti + 32 * a, c = tc + 32 * b;
+            T v = 0;
+            if (i < n && c < n) {
+                v = g.at(i, c);
+                dev = max(dev, fabs(v - ((i == c) ? (T)1 : (T)0)));
+            }
+            reg[a][b] = v;
+        }
+    if (check_identity) {
+        dev = wave_max_dpp(dev);
         if (lane == 0) red[wv] = dev;
         __syncthreads();
         if (tid == 0) {
@@ -82,67 +94,125 @@ __global__ __launch_bounds__(1024) void k_chol_inv(Mat<T> g, Mat<T> r_out, Mat<T
             if (!(mx <= ident_tol)) atomicOr(flag, 2);
         }
     }
-    __syncthreads();
 
-    // right-looking Cholesky, upper factor stored in the upper triangle of A
-    const int ti = tid >> 5, tc = tid & 31;
     for (int j = 0; j < n; ++j) {
-        T d = A[j * ld + j];
+        T *rb = rowbuf + (j & 1) * n;
+        const int ja = j >> 5, jt = j & 31;
+        if (ti == jt) {  // owners of row j publish it (unscaled; rb[j] is the pivot)
+#pragma unroll
+            for (int a = 0; a < NT; ++a)
+                if (a == ja) {
+#pragma unroll
+                    for (int b = 0; b < NT; ++b) {
+                        const int c = tc + 32 * b;
+                        if (c >= j && c < n) rb[c] = reg[a][b];
+                    }
+                }
+        }
+        __syncthreads();
+        T d = rb[j];
         if (!(d > (T)0)) {
             if (tid == 0) atomicOr(flag, 1);
             d = TNum<T>::tiny();
         }
-        const T rjj = sqrt(d);
-        __syncthreads();  // everyone has read the pivot
-        for (int c = j + tid; c < n; c += 1024) A[j * ld + c] = (c == j) ? rjj : A[j * ld + c] / rjj;
-        __syncthreads();
-        for (int i = j + 1 + ti; i < n; i += 32) {
-            const T rji = A[j * ld + i];
-            for (int c = j + 1 + tc; c < n; c += 32)
-                if (c >= i) A[i * ld + c] -= rji * A[j * ld + c];
-        }
-        __syncthreads();
-    }
-    for (int e = tid; e < n * n; e += 1024) {
-        int i = e / n, c = e % n;
-        r_out.at(i, c) = (c >= i) ? A[i * ld + c] : (T)0;
-    }
-    __syncthreads();
-    // in-place inverse of the upper triangle, column by column:
-    //   X[0:j, j] = -x_jj * X[0:j, 0:j] R[0:j, j],  x_jj = 1 / r_jj
-    for (int j = 0; j < n; ++j) {
-        for (int l = tid; l < j; l += 1024) svec[l] = A[l * ld + j];
-        const T xjj = (T)1 / A[j * ld + j];
-        __syncthreads();
-        for (int i = tid; i <= j; i += 1024) {
-            if (i == j) {
-                A[j * ld + j] = xjj;
-            } else {
-                T acc = 0;
-                for (int l = i; l < j; ++l) acc += A[i * ld + l] * svec[l];
-                A[i * ld + j] = -xjj * acc;
+        const T invr = fast_rsqrt(d), invd = invr * invr;
+        T cv[NT];
+#pragma unroll
+        for (int b = 0; b < NT; ++b) { const int c = tc + 32 * b; cv[b] = (c > j && c < n) ? rb[c] : (T)0; }
+#pragma unroll
+        for (int a = 0; a < NT; ++a) {
+            const int i = ti + 32 * a;
+            if (i == j) {  // row j becomes the final row of R
+#pragma unroll
+                for (int b = 0; b < NT; ++b) {
+                    const int c = tc + 32 * b;
+                    if (c >= j && c < n) reg[a][b] *= invr;
+                }
+            } else if (i > j && i < n) {
+                const T w = rb[i] * invd;
+#pragma unroll
+                for (int b = 0; b < NT; ++b) reg[a][b] -= w * cv[b];  // entries below the diagonal are never used
             }
         }
+    }
+    // R -> global and -> LDS (column j of R is broadcast from there during the inversion)
+#pragma unroll
+    for (int a = 0; a < NT; ++a)
+#pragma unroll
+        for (int b = 0; b < NT; ++b) {
+            const int i = ti + 32 * a, c = tc + 32 * b;
+            if (i < n && c < n) {
+                const T v = (c >= i) ? reg[a][b] : (T)0;
+                r_out.at(i, c) = v;
+                A[i * ld + c] = v;
+            }
+        }
+    // X = R^{-1} by Gauss-Jordan from the bottom row up, X register-tiled like the factor:
+    //   row j of X /= r_jj ; for i < j: row i -= R[i, j] * row j      (one barrier per step)
+#pragma unroll
+    for (int a = 0; a < NT; ++a)
+#pragma unroll
+        for (int b = 0; b < NT; ++b) reg[a][b] = (ti + 32 * a == tc + 32 * b) ? (T)1 : (T)0;
+    __syncthreads();
+    for (int j = n - 1; j >= 0; --j) {
+        T *rb = rowbuf + (j & 1) * n;
+        const int ja = j >> 5, jt = j & 31;
+        const T xs = fast_rcp(A[j * ld + j]);
+        if (ti == jt) {  // owners of row j scale it and publish it
+#pragma unroll
+            for (int a = 0; a < NT; ++a)
+                if (a == ja) {
+#pragma unroll
+                    for (int b = 0; b < NT; ++b) {
+                        const int c = tc + 32 * b;
+                        if (c >= j && c < n) { reg[a][b] *= xs; rb[c] = reg[a][b]; }
+                    }
+                }
+        }
         __syncthreads();
+        T cv[NT];
+#pragma unroll
+        for (int b = 0; b < NT; ++b) { const int c = tc + 32 * b; cv[b] = (c >= j && c < n) ? rb[c] : (T)0; }
+#pragma unroll
+        for (int a = 0; a < NT; ++a) {
+            const int i = ti + 32 * a;
+            if (i < j) {
+                const T w = A[i * ld + j];
+#pragma unroll
+                for (int b = 0; b < NT; ++b) reg[a][b] -= w * cv[b];
+            }
+        }
     }
-    for (int e = tid; e < n * n; e += 1024) {
-        int i = e / n, c = e % n;
-        rinv_out.at(i, c) = (c >= i) ? A[i * ld + c] : (T)0;
-    }
+#pragma unroll
+    for (int a = 0; a < NT; ++a)
+#pragma unroll
+        for (int b = 0; b < NT; ++b) {
+            const int i = ti + 32 * a, c = tc + 32 * b;
+            if (i < n && c < n) rinv_out.at(i, c) = (c >= i) ? reg[a][b] : (T)0;
+        }
 }
 
 template <typename T>
-static size_t chol_lds(int64_t n) { return ((size_t)n * (n | 1) + (size_t)n) * sizeof(T); }
+static size_t chol_lds(int64_t n) { return ((size_t)n * (n | 1) + 3 * (size_t)n + 16) * sizeof(T); }
 
-template <typename T>
-static void chol_inv(rc_context *c, Mat<T> g, Mat<T> r, Mat<T> rinv, bool check_identity, T ident_tol, int *flag) {
-    auto kern = k_chol_inv<T>;
+template <typename T, int NT>
+static void chol_inv_launch(rc_context *c, Mat<T> g, Mat<T> r, Mat<T> rinv, bool check_identity, T ident_tol, int *flag) {
+    auto kern = k_chol_inv<T, NT>;
     static bool attr_set[64] = {};
     if (!attr_set[c->device & 63]) {
         RC_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024));
         attr_set[c->device & 63] = true;
     }
     hipLaunchKernelGGL(kern, dim3(1), dim3(1024), chol_lds<T>(g.rows), c->stream, g, r, rinv, check_identity ? 1 : 0, ident_tol, flag);
+}
+template <typename T>
+static void chol_inv(rc_context *c, Mat<T> g, Mat<T> r, Mat<T> rinv, bool check_identity, T ident_tol, int *flag) {
+    const int64_t n = g.rows;
+    RC_REQUIRE(n <= 224 && chol_lds<T>(n) <= 160 * 1024 - 1024, RC_INVALID_ARGUMENT, "chol_inv: n = %lld does not fit LDS", (long long)n);
+    ProfScope ps(c, "op:chol_inv n=%lld", (long long)n);
+    if (n <= 64) chol_inv_launch<T, 2>(c, g, r, rinv, check_identity, ident_tol, flag);
+    else if (n <= 160) chol_inv_launch<T, 5>(c, g, r, rinv, check_identity, ident_tol, flag);
+    else chol_inv_launch<T, 7>(c, g, r, rinv, check_identity, ident_tol, flag);
 }
 
 template <typename T>
@@ -179,8 +249,23 @@ void tsqr_cholqr2(rc_context *c, Mat<T> y, Mat<T> q, Mat<T> r, int *flag) {
 //   rout : kmax x n, rout(i, p) = (i <= p) ? R(i, jp[p]) : 0      (may be empty)
 //   q2   : n x q2.cols = H_0 ... H_{kmax-1} [I ; 0]                 (may be empty)
 // ---------------------------------------------------------------------------
+template <typename T>
+__device__ inline T safe_hypot(T a, T b) {  // ?lapy2
+    a = fabs(a); b = fabs(b);
+    const T w = max(a, b), z = min(a, b);
+    if (z == (T)0) return w;
+    const T q = z * fast_rcp(w);
+    const T e = (T)1 + q * q;
+    return w * (e * fast_rsqrt(e));
+}
+template <typename T>
+__device__ inline T fast_sqrt_pos(T x) { return x > (T)0 ? x * fast_rsqrt(x) : (T)0; }
+
 template <typename T, int NE>
-__global__ __launch_bounds__(1024) void k_qrcp_small(Mat<T> rin, int kmax, int pivot, int64_t *jpvt_out, Mat<T> rout, Mat<T> q2) {
+__global__ __launch_bounds__(512) void k_qrcp_small(Mat<T> rin, int kmax, int pivot, int64_t *jpvt_out, Mat<T> rout, Mat<T> q2) {
+    constexpr int LPP = 8;     // lanes per column in the update
+    constexpr int NTHR = 512;  // 8 waves, 64 column groups
+    constexpr int NGRP = NTHR / LPP;
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     const int n = (int)rin.rows;
     const int ld = n | 1;
@@ -190,23 +275,23 @@ __global__ __launch_bounds__(1024) void k_qrcp_small(Mat<T> rin, int kmax, int p
     T *tau = vn2 + n;
     int *jp = reinterpret_cast<int *>(tau + n);
     const int tid = threadIdx.x, lane = tid & 63;
-    const int l16 = tid & 15, grp = tid >> 4;
+    const int ll = tid % LPP, grp = tid / LPP;
 
-    for (int e = tid; e < n * n; e += 1024) {
+    for (int e = tid; e < n * n; e += NTHR) {
         int i = e % n, cc = e / n;
         A[cc * ld + i] = rin.at(i, cc);
     }
     __syncthreads();
-    for (int p = grp; p < n; p += 64) {
+    for (int p = grp; p < n; p += NGRP) {
         T acc = 0;
-        for (int i = l16; i < n; i += 16) { T v = A[p * ld + i]; acc += v * v; }
-        acc = row_sum16(acc);
-        if (l16 == 0) { T nr = sqrt(acc); vn1[p] = nr; vn2[p] = nr; jp[p] = p; }
+        for (int i = ll; i < n; i += LPP) { T v = A[p * ld + i]; acc += v * v; }
+        acc = group_sum_dpp<LPP>(acc);
+        if (ll == 0) { T nr = sqrt(acc); vn1[p] = nr; vn2[p] = nr; jp[p] = p; }
     }
     __syncthreads();
 
     for (int j = 0; j < kmax; ++j) {
-        if (tid < 64) {  // wave 0: pivot search, "swap", reflector (?larfg)
+        if (tid < 64) {  // wave 0: pivot search (first maximum, like idamax), "swap", reflector (?larfg)
             if (pivot) {
                 T best = (T)-1;
                 int bi = 0x7fffffff;
@@ -214,13 +299,9 @@ __global__ __launch_bounds__(1024) void k_qrcp_small(Mat<T> rin, int kmax, int p
                     T v = fabs(vn1[p]);
                     if (v > best) { best = v; bi = p; }
                 }
-#pragma unroll
-                for (int off = 32; off > 0; off >>= 1) {
-                    T ob = __shfl_xor(best, off, 64);
-                    int oi = __shfl_xor(bi, off, 64);
-                    if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
-                }
-                const int pvt = (bi >= j && bi < n) ? bi : j;
+                const T mx = wave_max_dpp(best);
+                const int pv = wave_min_dpp(best == mx ? bi : 0x7fffffff);
+                const int pvt = (pv >= j && pv < n) ? pv : j;
                 if (lane == 0 && pvt != j) {
                     int t = jp[pvt]; jp[pvt] = jp[j]; jp[j] = t;
                     vn1[pvt] = vn1[j];
@@ -232,64 +313,66 @@ __global__ __launch_bounds__(1024) void k_qrcp_small(Mat<T> rin, int kmax, int p
             const T alpha = col[j];
             T acc = 0;
             for (int i = j + 1 + lane; i < n; i += 64) { T v = col[i]; acc += v * v; }
-            acc = wave_sum64(acc);
-            const T xnorm = sqrt(acc);
+            acc = wave_sum_dpp(acc);
+            const T xnorm = fast_sqrt_pos(acc);
             if (xnorm == (T)0) {
                 if (lane == 0) tau[j] = 0;
             } else {
-                const T beta = -copysign(hypot(alpha, xnorm), alpha);
-                const T scal = (T)1 / (alpha - beta);
+                const T beta = -copysign(safe_hypot(alpha, xnorm), alpha);
+                const T scal = fast_rcp(alpha - beta);
                 for (int i = j + 1 + lane; i < n; i += 64) col[i] *= scal;
-                if (lane == 0) { tau[j] = (beta - alpha) / beta; col[j] = beta; }
+                if (lane == 0) { tau[j] = (beta - alpha) * fast_rcp(beta); col[j] = beta; }
             }
         }
         __syncthreads();
-        {   // apply H_j to the remaining columns; one 16-lane group per column
+        {   // apply H_j to the remaining columns; one LPP-lane group per column
             const T tj = tau[j];
             const T *vcol = A + jp[j] * ld;
-            for (int p = j + 1 + grp; p < n; p += 64) {
+            T v[NE];
+#pragma unroll
+            for (int e = 0; e < NE; ++e) {
+                int i = j + ll + LPP * e;
+                v[e] = (i < n) ? ((i == j) ? (T)1 : vcol[i]) : (T)0;
+            }
+            for (int p = j + 1 + grp; p < n; p += NGRP) {
                 T *xcol = A + jp[p] * ld;
-                T x[NE], v[NE];
+                T x[NE];
                 T dot = 0;
 #pragma unroll
                 for (int e = 0; e < NE; ++e) {
-                    int i = j + l16 + 16 * e;
-                    x[e] = 0; v[e] = 0;
-                    if (i < n) {
-                        x[e] = xcol[i];
-                        v[e] = (i == j) ? (T)1 : vcol[i];
-                        dot += v[e] * x[e];
-                    }
+                    int i = j + ll + LPP * e;
+                    x[e] = (i < n) ? xcol[i] : (T)0;
+                    dot = fma(v[e], x[e], dot);
                 }
                 if (tj != (T)0) {
-                    dot = row_sum16(dot);
+                    dot = group_sum_dpp<LPP>(dot);
                     const T f = tj * dot;
 #pragma unroll
                     for (int e = 0; e < NE; ++e) {
-                        int i = j + l16 + 16 * e;
+                        int i = j + ll + LPP * e;
                         if (i < n) { x[e] -= f * v[e]; xcol[i] = x[e]; }
                     }
                 }
                 if (pivot) {
-                    const T xj = __shfl(x[0], lane & ~15, 64);
+                    const T xj = xcol[j];  // written by lane ll == 0 of this group: same wave, LDS ops are in order
                     const T vn = vn1[p];
                     if (vn != (T)0) {
-                        T t = fabs(xj) / vn;
+                        T t = fabs(xj) * fast_rcp(vn);
                         T temp = (T)1 - t * t;
                         temp = temp > (T)0 ? temp : (T)0;
-                        T rr = vn / vn2[p];
+                        T rr = vn * fast_rcp(vn2[p]);
                         T temp2 = temp * rr * rr;
                         if (temp2 <= TNum<T>::tol3z()) {
                             T ss = 0;
 #pragma unroll
                             for (int e = 0; e < NE; ++e) {
-                                int i = j + l16 + 16 * e;
+                                int i = j + ll + LPP * e;
                                 if (i > j && i < n) ss += x[e] * x[e];
                             }
-                            ss = row_sum16(ss);
-                            if (l16 == 0) { T nn = (j < n - 1) ? sqrt(ss) : (T)0; vn1[p] = nn; vn2[p] = nn; }
-                        } else if (l16 == 0) {
-                            vn1[p] = vn * sqrt(temp);
+                            ss = group_sum_dpp<LPP>(ss);
+                            if (ll == 0) { T nn = (j < n - 1) ? fast_sqrt_pos(ss) : (T)0; vn1[p] = nn; vn2[p] = nn; }
+                        } else if (ll == 0) {
+                            vn1[p] = vn * fast_sqrt_pos(temp);
                         }
                     }
                 }
@@ -298,19 +381,19 @@ __global__ __launch_bounds__(1024) void k_qrcp_small(Mat<T> rin, int kmax, int p
         __syncthreads();
     }
 
-    for (int p = tid; p < n; p += 1024) jpvt_out[p] = jp[p];
+    for (int p = tid; p < n; p += NTHR) jpvt_out[p] = jp[p];
     if (!rout.empty()) {
         const int64_t total = rout.rows * rout.cols;
-        for (int64_t e = tid; e < total; e += 1024) {
+        for (int64_t e = tid; e < total; e += NTHR) {
             int i = (int)(e / rout.cols), p = (int)(e % rout.cols);
             rout.at(i, p) = (i <= p) ? A[jp[p] * ld + i] : (T)0;
         }
     }
     if (!q2.empty()) {  // column cq of Q2: apply H_min(cq,kmax-1) ... H_0 to e_cq; A is read-only now
-        for (int cq = grp; cq < (int)q2.cols; cq += 64) {
+        for (int cq = grp; cq < (int)q2.cols; cq += NGRP) {
             T x[NE];
 #pragma unroll
-            for (int e = 0; e < NE; ++e) x[e] = (l16 + 16 * e == cq) ? (T)1 : (T)0;
+            for (int e = 0; e < NE; ++e) x[e] = (ll + LPP * e == cq) ? (T)1 : (T)0;
             for (int j = (cq < kmax - 1 ? cq : kmax - 1); j >= 0; --j) {
                 const T tj = tau[j];
                 if (tj == (T)0) continue;
@@ -319,18 +402,18 @@ __global__ __launch_bounds__(1024) void k_qrcp_small(Mat<T> rin, int kmax, int p
                 T dot = 0;
 #pragma unroll
                 for (int e = 0; e < NE; ++e) {
-                    int i = l16 + 16 * e;
+                    int i = ll + LPP * e;
                     v[e] = 0;
-                    if (i < n && i >= j) { v[e] = (i == j) ? (T)1 : vcol[i]; dot += v[e] * x[e]; }
+                    if (i < n && i >= j) { v[e] = (i == j) ? (T)1 : vcol[i]; dot = fma(v[e], x[e], dot); }
                 }
-                dot = row_sum16(dot);
+                dot = group_sum_dpp<LPP>(dot);
                 const T f = tj * dot;
 #pragma unroll
                 for (int e = 0; e < NE; ++e) x[e] -= f * v[e];
             }
 #pragma unroll
             for (int e = 0; e < NE; ++e) {
-                int i = l16 + 16 * e;
+                int i = ll + LPP * e;
                 if (i < n) q2.at(i, cq) = x[e];
             }
         }
@@ -352,11 +435,11 @@ void qrcp_small(rc_context *c, Mat<T> rin, int64_t kmax, bool pivot, int64_t *jp
             RC_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024)); \
             attr_set[c->device & 63] = true;                                                                           \
         }                                                                                                              \
-        hipLaunchKernelGGL(kern, dim3(1), dim3(1024), lds, c->stream, rin, (int)kmax, pivot ? 1 : 0, jpvt, rout, q2);  \
+        hipLaunchKernelGGL(kern, dim3(1), dim3(512), lds, c->stream, rin, (int)kmax, pivot ? 1 : 0, jpvt, rout, q2);   \
     } while (0)
-    if (n <= 64) RC_QS(4);
-    else if (n <= 144) RC_QS(9);
-    else RC_QS(13);
+    if (n <= 64) RC_QS(8);
+    else if (n <= 144) RC_QS(18);
+    else RC_QS(26);
 #undef RC_QS
 }
 
