@@ -11,6 +11,10 @@
 //    image keeps the operand's own contiguous dimension fastest, so global
 //    reads coalesce for either orientation and no transposing store is needed;
 //    row pitches are chosen so every fragment ds_read is bank-conflict free.
+//    When both operands are 16-byte aligned along their contiguous dimension
+//    (VEC = 2) the staging uses 2-element vector loads / LDS stores, and every
+//    thread keeps its global pointers in registers (no per-element 64-bit
+//    index arithmetic in the K loop).
 //  * Split-K with a DETERMINISTIC slab reduction (no float atomics): pivot
 //    decisions downstream must not depend on arrival order.
 //  * XCD-aware tile order: consecutive block ids land on different XCDs, so the
@@ -18,27 +22,35 @@
 //    share the B panel in that XCD's L2.
 #include "rc_common.hpp"
 
+#include <cstdlib>
+
 namespace rc {
 
 static __host__ __device__ inline int64_t cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
 typedef double double4_t __attribute__((ext_vector_type(4)));
 typedef float float4_t __attribute__((ext_vector_type(4)));
+typedef double double2_t __attribute__((ext_vector_type(2)));
+typedef float float2_t __attribute__((ext_vector_type(2)));
 
 template <typename T> struct Acc;
 template <> struct Acc<double> {
     typedef double4_t type;
+    typedef double2_t vec2;
     static __device__ inline type mfma(double a, double b, type c) { return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0); }
     static __device__ inline int row(int lane, int reg) { return (lane >> 4) + 4 * reg; }
 };
 template <> struct Acc<float> {
     typedef float4_t type;
+    typedef float2_t vec2;
     static __device__ inline type mfma(float a, float b, type c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
     static __device__ inline int row(int lane, int reg) { return 4 * (lane >> 4) + reg; }
 };
 
-// smallest pitch >= n with pitch % 32 == 16 (conflict-free M/N-fastest fragment reads)
+// smallest pitch >= n with pitch % 32 == 16 (conflict-free M/N-fastest fragment reads, 16x16x4 MFMA)
 constexpr int pitch16(int n) { return n + ((16 - n % 32) + 32) % 32; }
+// smallest pitch >= n with pitch % 8 == 4 (same for the 4x4x4 f64 MFMA fragments)
+constexpr int pitch4(int n) { return n + ((4 - n % 8) + 8) % 8; }
 
 template <typename T>
 struct GemmArgs {
@@ -55,28 +67,107 @@ struct GemmArgs {
     int tiles_m, tiles_n;
 };
 
-// ALAY: 0 = A is K-contiguous (sak == 1), 1 = A is M-contiguous (sam == 1)
-// BLAY: 0 = B is N-contiguous (sbn == 1), 1 = B is K-contiguous (sbk == 1)
-template <typename T, int ALAY, int BLAY, int BM, int BN, int BK, int WM, int WN>
+// One operand tile: R rows (the operand's non-reduction index) x BK, staged by NT threads.
+//   LAY == 0: the reduction index k is contiguous in memory (stride_k == 1 when VEC == 2)
+//   LAY == 1: the row index is contiguous in memory (stride_r == 1 when VEC == 2)
+// LDS image: LAY == 0 -> [R][P], P = BK + 2 (16x16x4 MFMA fragments) or BK + 8 (4x4x4 fragments);
+//            LAY == 1 -> [BK][P], P = pitch16(R) or pitch4(R).  Both choices make every fragment
+//            ds_read_b64 of the corresponding MFMA shape bank-conflict free.
+template <typename T, int LAY, int R, int BK, int NT, int VEC, int MODE = 0>
+struct TileStager {
+    static constexpr int P = LAY == 0 ? (MODE == 0 ? BK + 2 : BK + 8) : (MODE == 0 ? pitch16(R) : pitch4(R));
+    static constexpr int ELEMS = LAY == 0 ? R * P : BK * P;
+    static constexpr int NVEC = R * BK / VEC;
+    static constexpr int PER_T = (NVEC + NT - 1) / NT;
+    typedef typename Acc<T>::vec2 vec2;
+
+    const T *ptr[PER_T];  // global address of the vector at k-step 0
+    T val[PER_T][VEC];
+
+    static __device__ inline void coords(int idx, int &r, int &k) {
+        if (LAY == 0) { k = (idx % (BK / VEC)) * VEC; r = idx / (BK / VEC); }
+        else { r = (idx % (R / VEC)) * VEC; k = idx / (R / VEC); }
+    }
+    __device__ inline void init(const T *base, int64_t r0, int64_t kbeg, int64_t sr, int64_t sk, int tid) {
+#pragma unroll
+        for (int e = 0; e < PER_T; ++e) {
+            int r, k;
+            coords(tid + e * NT, r, k);
+            ptr[e] = base + (r0 + r) * sr + (kbeg + k) * sk;
+        }
+    }
+    // loads the tile whose first reduction index is k0 (absolute); koff_elems = (k0 - kbeg) * sk
+    __device__ inline void load(int64_t r0, int64_t rmax, int64_t k0, int64_t kend, int64_t koff_elems, int64_t sr, int64_t sk, int tid) {
+#pragma unroll
+        for (int e = 0; e < PER_T; ++e) {
+            const int idx = tid + e * NT;
+            int r, k;
+            coords(idx, r, k);
+            const T *p = ptr[e] + koff_elems;
+            const int64_t gr = r0 + r, gk = k0 + k;
+#pragma unroll
+            for (int v = 0; v < VEC; ++v) val[e][v] = 0;
+            if (idx < NVEC) {
+                if (VEC == 2) {
+                    const bool full = LAY == 0 ? (gr < rmax && gk + 2 <= kend) : (gr + 2 <= rmax && gk < kend);
+                    if (full) {
+                        const vec2 t = *reinterpret_cast<const vec2 *>(p);
+                        val[e][0] = t[0];
+                        val[e][VEC - 1] = t[1];
+                    } else {
+#pragma unroll
+                        for (int v = 0; v < VEC; ++v) {
+                            const int64_t r2 = LAY == 0 ? gr : gr + v, k2 = LAY == 0 ? gk + v : gk;
+                            if (r2 < rmax && k2 < kend) val[e][v] = p[LAY == 0 ? v * sk : v * sr];
+                        }
+                    }
+                } else {
+                    if (gr < rmax && gk < kend) val[e][0] = *p;
+                }
+            }
+        }
+    }
+    __device__ inline void store(T *lds, int tid) const {
+#pragma unroll
+        for (int e = 0; e < PER_T; ++e) {
+            const int idx = tid + e * NT;
+            int r, k;
+            coords(idx, r, k);
+            const int off = LAY == 0 ? r * P + k : k * P + r;
+            if (idx < NVEC) {
+                if (VEC == 2) {
+                    vec2 t;
+                    t[0] = val[e][0];
+                    t[1] = val[e][VEC - 1];
+                    *reinterpret_cast<vec2 *>(lds + off) = t;
+                } else {
+                    lds[off] = val[e][0];
+                }
+            }
+        }
+    }
+};
+
+// ALAY: 0 = A is K-contiguous, 1 = A is M-contiguous ; BLAY: 0 = B is N-contiguous, 1 = B is K-contiguous
+// NBUF: 2 = double-buffered LDS (one barrier per K step), 1 = single LDS buffer + register
+// prefetch (two barriers per K step, half the LDS: deeper BK or more workgroups per CU)
+template <typename T, int ALAY, int BLAY, int BM, int BN, int BK, int WM, int WN, int VEC, int NBUF>
 __global__ __launch_bounds__(WM *WN * 64) void k_gemm_mfma(GemmArgs<T> g) {
     constexpr int NT = WM * WN * 64;
     constexpr int TM = BM / WM / 16;  // 16x16 tiles per wave along M
     constexpr int TN = BN / WN / 16;
     static_assert(BM % (WM * 16) == 0 && BN % (WN * 16) == 0 && BK % 4 == 0, "tile shape");
-    // LDS pitches (elements): fastest dimension mirrors the global contiguity.
-    //  K-fastest image [rows][BK + 2]  : fragment address r*P + kk, P = BK+2 (== 2 mod 4) -> conflict free
-    //  M/N-fastest image [BK][BX + pad]: fragment address kk*P + r, P == 16 mod 32        -> conflict free
-    constexpr int PA = ALAY == 0 ? BK + 2 : pitch16(BM);
-    constexpr int PB = BLAY == 1 ? BK + 2 : pitch16(BN);
-    constexpr int A_ELEMS = ALAY == 0 ? BM * PA : BK * PA;
-    constexpr int B_ELEMS = BLAY == 1 ? BN * PB : BK * PB;
-    constexpr int A_PER_T = (BM * BK + NT - 1) / NT;
-    constexpr int B_PER_T = (BN * BK + NT - 1) / NT;
+    typedef TileStager<T, ALAY, BM, BK, NT, VEC> StA;               // rows = m
+    typedef TileStager<T, BLAY == 1 ? 0 : 1, BN, BK, NT, VEC> StB;  // rows = n (B N-contiguous == row-contiguous)
+    constexpr int PA = StA::P, PB = StB::P;
+    constexpr int A_ELEMS = StA::ELEMS, B_ELEMS = StB::ELEMS;
 
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     T *smem = reinterpret_cast<T *>(smem_raw);
-    T *As[2] = {smem, smem + A_ELEMS + B_ELEMS};
-    T *Bs[2] = {smem + A_ELEMS, smem + 2 * A_ELEMS + B_ELEMS};
+    // LDS addresses are formed arithmetically from the one __shared__ array (an array of
+    // pointers would decay to generic pointers: flat_load instead of ds_read, and every
+    // fragment read would then also wait for the global prefetch, vmcnt(0))
+    constexpr int STAGE = NBUF == 2 ? A_ELEMS + B_ELEMS : 0;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
@@ -101,59 +192,27 @@ __global__ __launch_bounds__(WM *WN * 64) void k_gemm_mfma(GemmArgs<T> g) {
 #pragma unroll
         for (int j = 0; j < TN; ++j) acc[i][j] = typename Acc<T>::type{0, 0, 0, 0};
 
-    T ra[A_PER_T], rb[B_PER_T];
-
-    auto load_tiles = [&](int64_t k0) {
-#pragma unroll
-        for (int e = 0; e < A_PER_T; ++e) {
-            int idx = tid + e * NT;
-            int mm, kk;
-            if (ALAY == 0) { kk = idx % BK; mm = idx / BK; } else { mm = idx % BM; kk = idx / BM; }
-            int64_t gm = m0 + mm, gk = k0 + kk;
-            T v = 0;
-            if (idx < BM * BK && gm < g.M && gk < kend) v = g.a[gm * g.sam + gk * g.sak];
-            ra[e] = v;
-        }
-#pragma unroll
-        for (int e = 0; e < B_PER_T; ++e) {
-            int idx = tid + e * NT;
-            int nn, kk;
-            if (BLAY == 1) { kk = idx % BK; nn = idx / BK; } else { nn = idx % BN; kk = idx / BN; }
-            int64_t gn = n0 + nn, gk = k0 + kk;
-            T v = 0;
-            if (idx < BN * BK && gn < g.N && gk < kend) v = g.b[gk * g.sbk + gn * g.sbn];
-            rb[e] = v;
-        }
-    };
-    auto store_tiles = [&](int buf) {
-#pragma unroll
-        for (int e = 0; e < A_PER_T; ++e) {
-            int idx = tid + e * NT;
-            if (idx < BM * BK) {
-                if (ALAY == 0) As[buf][(idx / BK) * PA + (idx % BK)] = ra[e];
-                else As[buf][(idx / BM) * PA + (idx % BM)] = ra[e];
-            }
-        }
-#pragma unroll
-        for (int e = 0; e < B_PER_T; ++e) {
-            int idx = tid + e * NT;
-            if (idx < BN * BK) {
-                if (BLAY == 1) Bs[buf][(idx / BK) * PB + (idx % BK)] = rb[e];
-                else Bs[buf][(idx / BN) * PB + (idx % BN)] = rb[e];
-            }
-        }
-    };
+    StA sa;
+    StB sb;
+    sa.init(g.a, m0, kbeg, g.sam, g.sak, tid);
+    sb.init(g.b, n0, kbeg, g.sbn, g.sbk, tid);
 
     const int64_t nk = kend > kbeg ? cdiv(kend - kbeg, BK) : 0;
     if (nk > 0) {
-        load_tiles(kbeg);
-        store_tiles(0);
+        sa.load(m0, g.M, kbeg, kend, 0, g.sam, g.sak, tid);
+        sb.load(n0, g.N, kbeg, kend, 0, g.sbn, g.sbk, tid);
+        sa.store(smem, tid);
+        sb.store(smem + A_ELEMS, tid);
     }
     __syncthreads();
     for (int64_t it = 0; it < nk; ++it) {
         const int buf = (int)(it & 1);
-        if (it + 1 < nk) load_tiles(kbeg + (it + 1) * BK);  // global loads in flight during the MFMAs
-        const T *as = As[buf], *bs = Bs[buf];
+        if (it + 1 < nk) {  // global loads in flight during the MFMAs
+            const int64_t koff = (it + 1) * BK;
+            sa.load(m0, g.M, kbeg + koff, kend, koff * g.sak, g.sam, g.sak, tid);
+            sb.load(n0, g.N, kbeg + koff, kend, koff * g.sbk, g.sbn, g.sbk, tid);
+        }
+        const T *as = smem + buf * STAGE, *bs = smem + A_ELEMS + buf * STAGE;
 #pragma unroll
         for (int ks = 0; ks < BK / 4; ++ks) {
             T af[TM], bf[TN];
@@ -172,7 +231,11 @@ __global__ __launch_bounds__(WM *WN * 64) void k_gemm_mfma(GemmArgs<T> g) {
 #pragma unroll
                 for (int j = 0; j < TN; ++j) acc[i][j] = Acc<T>::mfma(af[i], bf[j], acc[i][j]);
         }
-        if (it + 1 < nk) store_tiles(buf ^ 1);  // the other buffer was last read one iteration ago
+        if (NBUF == 1) __syncthreads();  // everyone is done reading the single buffer
+        if (it + 1 < nk) {  // NBUF == 2: the other buffer was last read one iteration ago
+            sa.store(smem + (buf ^ 1) * STAGE, tid);
+            sb.store(smem + A_ELEMS + (buf ^ 1) * STAGE, tid);
+        }
         __syncthreads();
     }
 
@@ -197,6 +260,140 @@ __global__ __launch_bounds__(WM *WN * 64) void k_gemm_mfma(GemmArgs<T> g) {
             }
 }
 
+// ---------------------------------------------------------------------------
+// f64 GEMM on v_mfma_f64_4x4x4_4b_f64.
+//
+// Measured on MI355X (tools/microbench, profiles/r01_microbench_mfma_f64.txt): the 16x16x4
+// f64 MFMA sustains only 35-49 TFLOP/s, the 4x4x4 four-block form 70-75 TFLOP/s (the
+// 78.6 TFLOP/s datasheet rate) once >= ~64 independent accumulators are in flight, so every
+// f64 product of the hot path uses this shape.
+//
+// Lane layout (probed, tools/microbench/mfma_f64_4x4x4_layout.hip): with kl = l >> 4,
+// b = (l >> 2) & 3, i/j = l & 3:
+//   A: lane holds A_b[i][kl];  B: lane holds B_b[kl][j];  D: lane l = 16*i + 4*b + j holds D_b[i][j]
+// for four independent blocks b.  The blocks are used as four output sub-tiles that SHARE one
+// operand (an LDS broadcast read):
+//   ORIENT 0: A shared  -> one instruction is a  4 x 16 x 4 product (row = l >> 4, col = l & 15)
+//   ORIENT 1: B shared  -> one instruction is a 16 x  4 x 4 product
+// so all 64 result lanes are distinct outputs, rows of C are written in 128-byte segments
+// (ORIENT 0) and the LDS images / pitches are exactly those of the 16x16x4 kernel.
+// ---------------------------------------------------------------------------
+template <int ALAY, int BLAY, int BM, int BN, int BK, int WM, int WN, int VEC, int ORIENT>
+__global__ __launch_bounds__(WM *WN * 64) void k_gemm_f64q(GemmArgs<double> g) {
+    typedef double T;
+    constexpr int NT = WM * WN * 64;
+    constexpr int WR = BM / WM, WC = BN / WN;               // wave tile
+    constexpr int TM = ORIENT == 0 ? WR / 4 : WR / 16;      // micro tiles per wave along M
+    constexpr int TN = ORIENT == 0 ? WC / 16 : WC / 4;
+    static_assert(BM % WM == 0 && BN % WN == 0 && BK % 4 == 0, "tile shape");
+    static_assert(ORIENT == 0 ? (WR % 4 == 0 && WC % 16 == 0) : (WR % 16 == 0 && WC % 4 == 0), "wave tile shape");
+    typedef TileStager<T, ALAY, BM, BK, NT, VEC> StA;
+    typedef TileStager<T, BLAY == 1 ? 0 : 1, BN, BK, NT, VEC> StB;
+    constexpr int PA = StA::P, PB = StB::P;
+    constexpr int A_ELEMS = StA::ELEMS, B_ELEMS = StB::ELEMS;
+
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    T *smem = reinterpret_cast<T *>(smem_raw);
+    constexpr int STAGE = A_ELEMS + B_ELEMS;  // see k_gemm_mfma: keep LDS pointers out of arrays
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int lk = lane >> 4;
+    // lane's row inside an A micro tile / column inside a B micro tile
+    const int la = ORIENT == 0 ? (lane & 3) : (lane & 15);
+    const int lbn = ORIENT == 0 ? (lane & 15) : (lane & 3);
+
+    const int ntiles = g.tiles_m * g.tiles_n;
+    int bid = blockIdx.x;
+    {
+        const int q = ntiles / 8, r = ntiles % 8, xcd = bid % 8, idx = bid / 8;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    const int tile_n = bid % g.tiles_n, tile_m = bid / g.tiles_n;
+    const int64_t m0 = (int64_t)tile_m * BM, n0 = (int64_t)tile_n * BN;
+    const int split = blockIdx.y;
+    const int64_t kbeg = (int64_t)split * g.kchunk;
+    const int64_t kend = min(g.K, kbeg + g.kchunk);
+
+    double acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = 0.0;
+
+    StA sa;
+    StB sb;
+    sa.init(g.a, m0, kbeg, g.sam, g.sak, tid);
+    sb.init(g.b, n0, kbeg, g.sbn, g.sbk, tid);
+
+    const int64_t nk = kend > kbeg ? cdiv(kend - kbeg, BK) : 0;
+    if (nk > 0) {
+        sa.load(m0, g.M, kbeg, kend, 0, g.sam, g.sak, tid);
+        sb.load(n0, g.N, kbeg, kend, 0, g.sbn, g.sbk, tid);
+        sa.store(smem, tid);
+        sb.store(smem + A_ELEMS, tid);
+    }
+    __syncthreads();
+    constexpr int AM = ORIENT == 0 ? 4 : 16, BNW = ORIENT == 0 ? 16 : 4;
+    for (int64_t it = 0; it < nk; ++it) {
+        const int buf = (int)(it & 1);
+        if (it + 1 < nk) {
+            const int64_t koff = (it + 1) * BK;
+            sa.load(m0, g.M, kbeg + koff, kend, koff * g.sak, g.sam, g.sak, tid);
+            sb.load(n0, g.N, kbeg + koff, kend, koff * g.sbk, g.sbn, g.sbk, tid);
+        }
+        const T *as = smem + buf * STAGE, *bs = smem + A_ELEMS + buf * STAGE;
+        // not unrolled: with all BK/4 sub-steps in flight the hoisted fragment loads (4 x 17 f64
+        // registers) spill; one sub-step = (TM + TN) LDS reads feeding TM * TN MFMAs
+#pragma unroll 1
+        for (int ks = 0; ks < BK / 4; ++ks) {
+            T af[TM], bf[TN];
+            const int kk = ks * 4 + lk;
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                const int mm = wm * WR + i * AM + la;
+                af[i] = ALAY == 0 ? as[mm * PA + kk] : as[kk * PA + mm];
+            }
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int nn = wn * WC + j * BNW + lbn;
+                bf[j] = BLAY == 1 ? bs[nn * PB + kk] : bs[kk * PB + nn];
+            }
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f64_4x4x4f64(af[i], bf[j], acc[i][j], 0, 0, 0);
+        }
+        if (it + 1 < nk) {
+            sa.store(smem + (buf ^ 1) * STAGE, tid);
+            sb.store(smem + A_ELEMS + (buf ^ 1) * STAGE, tid);
+        }
+        __syncthreads();
+    }
+
+    // ---- epilogue: D lane l = 16*i + 4*b + j ---------------------------------------------
+    //   ORIENT 0: row = i (l >> 4),           col = 4*b + j (l & 15)
+    //   ORIENT 1: row = 4*b + i,              col = j (l & 3)
+    const int er = ORIENT == 0 ? (lane >> 4) : (((lane >> 2) & 3) * 4 + (lane >> 4));
+    const int ec = ORIENT == 0 ? (lane & 15) : (lane & 3);
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int64_t gm = m0 + wm * WR + i * AM + er;
+            const int64_t gn = n0 + wn * WC + j * BNW + ec;
+            if (gm < g.M && gn < g.N) {
+                const double v = acc[i][j];
+                if (g.splits > 1) {
+                    g.partial[((int64_t)split * g.M + gm) * g.N + gn] = v;
+                } else {
+                    T *cp = g.c + gm * g.scm + gn * g.scn;
+                    *cp = g.beta == 0.0 ? g.alpha * v : g.alpha * v + g.beta * (*cp);
+                }
+            }
+        }
+}
+
 // C = alpha * sum_s partial[s] + beta * C ; fixed summation order => deterministic
 template <typename T>
 __global__ __launch_bounds__(256) void k_splitk_reduce(GemmArgs<T> g) {
@@ -213,29 +410,35 @@ __global__ __launch_bounds__(256) void k_splitk_reduce(GemmArgs<T> g) {
     }
 }
 
-template <typename T, int ALAY, int BLAY, int BM, int BN, int BK, int WM, int WN>
+static int env_int(const char *name, int dflt) {
+    const char *e = getenv(name);
+    return e ? atoi(e) : dflt;
+}
+
+template <typename T, int ALAY, int BLAY, int BM, int BN, int BK, int WM, int WN, int VEC, int NBUF = 2>
 static void launch_cfg(rc_context *c, GemmArgs<T> g) {
-    constexpr int PA = ALAY == 0 ? BK + 2 : pitch16(BM);
-    constexpr int PB = BLAY == 1 ? BK + 2 : pitch16(BN);
-    constexpr int A_ELEMS = ALAY == 0 ? BM * PA : BK * PA;
-    constexpr int B_ELEMS = BLAY == 1 ? BN * PB : BK * PB;
-    constexpr size_t lds = 2 * (size_t)(A_ELEMS + B_ELEMS) * sizeof(T);
+    constexpr int NT = WM * WN * 64;
+    typedef TileStager<T, ALAY, BM, BK, NT, VEC> StA;
+    typedef TileStager<T, BLAY == 1 ? 0 : 1, BN, BK, NT, VEC> StB;
+    constexpr size_t lds = NBUF * (size_t)(StA::ELEMS + StB::ELEMS) * sizeof(T);
+    static_assert(lds <= 160 * 1024, "tile does not fit LDS");
     g.tiles_m = (int)cdiv(g.M, BM);
     g.tiles_n = (int)cdiv(g.N, BN);
     const int64_t tiles = (int64_t)g.tiles_m * g.tiles_n;
-    // split K until the grid covers the 256 CUs about twice (only worth it for deep K)
+    // Split K until the grid covers the 256 CUs about twice (only worth it for deep K; tiny
+    // outputs with a deep reduction -- the n x n Gram matrices of the CholeskyQR passes --
+    // need up to 128 slabs to reach every CU).
+    static const int target = env_int("RC_GEMM_TARGET_WGS", 256);
     int splits = 1;
     const int64_t ksteps = cdiv(g.K, BK);
-    // (tiny outputs with a deep reduction -- the n x n Gram matrices of the CholeskyQR passes --
-    //  need up to 128 slabs to reach every CU)
-    while (tiles * splits < 384 && splits < 128 && ksteps / (splits * 2) >= (tiles >= 32 ? 16 : 4)) splits *= 2;
+    while (tiles * splits < target && splits < 128 && ksteps / (splits * 2) >= (tiles >= 32 ? 16 : 4)) splits *= 2;
     g.kchunk = cdiv(cdiv(g.K, splits), BK) * BK;
     splits = (int)cdiv(g.K, g.kchunk);
     if (splits < 1) splits = 1;
     g.splits = splits;
     ArenaMark mark(c);
     if (splits > 1) g.partial = c->alloc<T>((size_t)splits * g.M * g.N);
-    auto kern = k_gemm_mfma<T, ALAY, BLAY, BM, BN, BK, WM, WN>;
+    auto kern = k_gemm_mfma<T, ALAY, BLAY, BM, BN, BK, WM, WN, VEC, NBUF>;
     static bool attr_set[64] = {};
     if (lds > 48 * 1024 && !attr_set[c->device & 63]) {
         RC_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -243,7 +446,7 @@ static void launch_cfg(rc_context *c, GemmArgs<T> g) {
     }
     {
         ProfScope ps(c, "kernel:k_gemm_mfma<%s> M=%lld N=%lld K=%lld", sizeof(T) == 8 ? "f64" : "f32", (long long)g.M, (long long)g.N, (long long)g.K);
-        hipLaunchKernelGGL(kern, dim3((unsigned)tiles, (unsigned)splits), dim3(WM * WN * 64), lds, c->stream, g);
+        hipLaunchKernelGGL(kern, dim3((unsigned)tiles, (unsigned)splits), dim3(NT), lds, c->stream, g);
     }
     if (splits > 1) {
         ProfScope ps(c, "kernel:k_splitk_reduce M=%lld N=%lld splits=%d", (long long)g.M, (long long)g.N, splits);
@@ -252,17 +455,93 @@ static void launch_cfg(rc_context *c, GemmArgs<T> g) {
     }
 }
 
-template <typename T, int ALAY, int BLAY>
+template <int ALAY, int BLAY, int BM, int BN, int BK, int WM, int WN, int VEC, int ORIENT>
+static void launch_f64q(rc_context *c, GemmArgs<double> g) {
+    typedef double T;
+    constexpr int NT = WM * WN * 64;
+    typedef TileStager<T, ALAY, BM, BK, NT, VEC> StA;
+    typedef TileStager<T, BLAY == 1 ? 0 : 1, BN, BK, NT, VEC> StB;
+    constexpr size_t lds = 2 * (size_t)(StA::ELEMS + StB::ELEMS) * sizeof(T);
+    static_assert(lds <= 160 * 1024, "tile does not fit LDS");
+    g.tiles_m = (int)cdiv(g.M, BM);
+    g.tiles_n = (int)cdiv(g.N, BN);
+    const int64_t tiles = (int64_t)g.tiles_m * g.tiles_n;
+    static const int target = env_int("RC_GEMM_TARGET_WGS", 256);
+    int splits = 1;
+    const int64_t ksteps = cdiv(g.K, BK);
+    while (tiles * splits < target && splits < 128 && ksteps / (splits * 2) >= (tiles >= 32 ? 16 : 4)) splits *= 2;
+    g.kchunk = cdiv(cdiv(g.K, splits), BK) * BK;
+    splits = (int)cdiv(g.K, g.kchunk);
+    if (splits < 1) splits = 1;
+    g.splits = splits;
+    ArenaMark mark(c);
+    if (splits > 1) g.partial = c->alloc<T>((size_t)splits * g.M * g.N);
+    auto kern = k_gemm_f64q<ALAY, BLAY, BM, BN, BK, WM, WN, VEC, ORIENT>;
+    static bool attr_set[64] = {};
+    if (lds > 48 * 1024 && !attr_set[c->device & 63]) {
+        RC_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_set[c->device & 63] = true;
+    }
+    {
+        ProfScope ps(c, "kernel:k_gemm_mfma<f64> M=%lld N=%lld K=%lld", (long long)g.M, (long long)g.N, (long long)g.K);
+        hipLaunchKernelGGL(kern, dim3((unsigned)tiles, (unsigned)splits), dim3(NT), lds, c->stream, g);
+    }
+    if (splits > 1) {
+        ProfScope ps(c, "kernel:k_splitk_reduce M=%lld N=%lld splits=%d", (long long)g.M, (long long)g.N, splits);
+        int grid = (int)std::min<int64_t>(cdiv(g.M * g.N, 256), 4096);
+        hipLaunchKernelGGL(k_splitk_reduce<T>, dim3(grid), dim3(256), 0, c->stream, g);
+    }
+}
+
+// f64 shapes on the 4x4x4 MFMA (RC_GEMM_F64X4=0 falls back to the 16x16x4 kernel)
+template <int ALAY, int BLAY, int VEC>
+static bool launch_shape_f64q(rc_context *c, const GemmArgs<double> &g) {
+    static const int use = env_int("RC_GEMM_F64X4", 1);
+    if (!use) return false;
+    if (g.M <= 144 && g.N <= 144 && g.M > 80 && g.N > 80) launch_f64q<ALAY, BLAY, 144, 144, 16, 3, 3, VEC, 0>(c, g);
+    else if (g.N <= 80) launch_f64q<ALAY, BLAY, 256, 80, 16, 8, 1, VEC, 0>(c, g);
+    else if (g.N <= 144) launch_f64q<ALAY, BLAY, 256, 144, 16, 8, 1, VEC, 0>(c, g);
+    else if (g.M <= 80) launch_f64q<ALAY, BLAY, 80, 256, 16, 1, 8, VEC, 1>(c, g);
+    else if (g.M <= 144) launch_f64q<ALAY, BLAY, 144, 256, 16, 1, 8, VEC, 1>(c, g);
+    else launch_f64q<ALAY, BLAY, 128, 128, 16, 2, 2, VEC, 0>(c, g);
+    return true;
+}
+template <typename T, int ALAY, int BLAY, int VEC>
+struct F64Q { static bool run(rc_context *, const GemmArgs<T> &) { return false; } };
+template <int ALAY, int BLAY, int VEC>
+struct F64Q<double, ALAY, BLAY, VEC> { static bool run(rc_context *c, const GemmArgs<double> &g) { return launch_shape_f64q<ALAY, BLAY, VEC>(c, g); } };
+
+template <typename T, int ALAY, int BLAY, int VEC>
 static void launch_shape(rc_context *c, const GemmArgs<T> &g) {
+    if (F64Q<T, ALAY, BLAY, VEC>::run(c, g)) return;
     // Skinny outputs (the sketch Y = A Omega has N = k + p ~ 69..133; the range
     // projection B = Q^H A has M = k ~ 64..128) get tiles that cover the short
     // side once, so the long operand streams from HBM exactly once.
-    if (g.M <= 144 && g.N <= 144 && g.M > 80 && g.N > 80) launch_cfg<T, ALAY, BLAY, 144, 144, 16, 3, 3>(c, g);
-    else if (g.N <= 80) launch_cfg<T, ALAY, BLAY, 128, 80, 16, 4, 1>(c, g);
-    else if (g.N <= 144) launch_cfg<T, ALAY, BLAY, 128, 144, 16, 4, 1>(c, g);
-    else if (g.M <= 80) launch_cfg<T, ALAY, BLAY, 80, 128, 16, 1, 4>(c, g);
-    else if (g.M <= 144) launch_cfg<T, ALAY, BLAY, 144, 128, 16, 1, 4>(c, g);
-    else launch_cfg<T, ALAY, BLAY, 128, 128, 16, 2, 2>(c, g);
+    static const int vn = env_int("RC_GEMM_SKINNY_N", 0), vm = env_int("RC_GEMM_SKINNY_M", 0);
+    if (g.M <= 144 && g.N <= 144 && g.M > 80 && g.N > 80) launch_cfg<T, ALAY, BLAY, 144, 144, 16, 3, 3, VEC>(c, g);
+    else if (g.N <= 80) launch_cfg<T, ALAY, BLAY, 128, 80, 16, 4, 1, VEC>(c, g);
+    else if (g.N <= 144) {
+        if (vn == 1) launch_cfg<T, ALAY, BLAY, 128, 144, 16, 4, 1, VEC>(c, g);
+        else launch_cfg<T, ALAY, BLAY, 256, 144, 16, 8, 1, VEC>(c, g);
+    } else if (g.M <= 80) launch_cfg<T, ALAY, BLAY, 80, 128, 16, 1, 4, VEC>(c, g);
+    else if (g.M <= 144) {
+        if (vm == 1) launch_cfg<T, ALAY, BLAY, 144, 128, 16, 1, 4, VEC>(c, g);
+        else launch_cfg<T, ALAY, BLAY, 144, 256, 16, 1, 8, VEC>(c, g);
+    } else launch_cfg<T, ALAY, BLAY, 128, 128, 16, 2, 2, VEC>(c, g);
+}
+
+template <typename T, int ALAY, int BLAY>
+static void launch_vec(rc_context *c, const GemmArgs<T> &g) {
+    // 2-element vector staging needs the contiguous stride to be 1, the other stride even and
+    // the base 2-element aligned, for BOTH operands (odd leading dimensions take the scalar path)
+    auto ok = [](const T *p, int64_t s_contig, int64_t s_other) {
+        return s_contig == 1 && (s_other % 2) == 0 && (reinterpret_cast<uintptr_t>(p) % (2 * sizeof(T))) == 0;
+    };
+    const bool va = ALAY == 0 ? ok(g.a, g.sak, g.sam) : ok(g.a, g.sam, g.sak);
+    const bool vb = BLAY == 0 ? ok(g.b, g.sbn, g.sbk) : ok(g.b, g.sbk, g.sbn);
+    static const int allow = env_int("RC_GEMM_VEC", 1);
+    if (va && vb && allow) launch_shape<T, ALAY, BLAY, 2>(c, g);
+    else launch_shape<T, ALAY, BLAY, 1>(c, g);
 }
 
 template <typename T>
@@ -299,9 +578,9 @@ void gemm(rc_context *c, T alpha, Mat<T> a, Mat<T> b, T beta, Mat<T> cm) {
     const bool a_kc = (a.cs == 1);
     const bool b_nc = (b.cs == 1);
     if (a_kc) {
-        if (b_nc) launch_shape<T, 0, 0>(c, g); else launch_shape<T, 0, 1>(c, g);
+        if (b_nc) launch_vec<T, 0, 0>(c, g); else launch_vec<T, 0, 1>(c, g);
     } else {
-        if (b_nc) launch_shape<T, 1, 0>(c, g); else launch_shape<T, 1, 1>(c, g);
+        if (b_nc) launch_vec<T, 1, 0>(c, g); else launch_vec<T, 1, 1>(c, g);
     }
 }
 

@@ -419,11 +419,11 @@ void form_q(rc_context *c, Mat<T> w, const int64_t *jpvt, const T *tau, int64_t 
         // tall: three MFMA GEMMs instead of k dependent reflector applications per column
         ArenaMark mark(c);
         const int64_t kq = qw.cols;
-        Mat<T> vm = colmajor(c->alloc<T>((size_t)m * k), m, k, m);
+        Mat<T> vm = colmajor(c->alloc<T>((size_t)even_ld(m) * k), m, k, even_ld(m));
         hipLaunchKernelGGL(k_extract_v<T>, dim3((unsigned)std::min<int64_t>(cdiv(m, 256), 64), (unsigned)k), dim3(256), 0, c->stream, w, jpvt, vm);
-        Mat<T> sg = rowmajor(c->alloc<T>((size_t)k * k), k, k, k);
+        Mat<T> sg = rowmajor(c->alloc<T>((size_t)k * even_ld(k)), k, k, even_ld(k));
         gemm<T>(c, 1, vm.t(), vm, 0, sg);
-        Mat<T> tm = colmajor(c->alloc<T>((size_t)k * k), k, k, k);
+        Mat<T> tm = colmajor(c->alloc<T>((size_t)even_ld(k) * k), k, k, even_ld(k));
         {
             const size_t lds = ((size_t)k + (size_t)k * (k | 1)) * sizeof(T);
             RC_REQUIRE(lds <= 160 * 1024 - 1024, RC_INVALID_ARGUMENT, "form_q: block of %lld reflectors does not fit the LDS T-builder", (long long)k);
@@ -435,7 +435,7 @@ void form_q(rc_context *c, Mat<T> w, const int64_t *jpvt, const T *tau, int64_t 
             }
             hipLaunchKernelGGL(kern, dim3(1), dim3(1024), lds, c->stream, sg, tau, tm);
         }
-        Mat<T> w2 = rowmajor(c->alloc<T>((size_t)k * kq), k, kq, kq);
+        Mat<T> w2 = rowmajor(c->alloc<T>((size_t)k * even_ld(kq)), k, kq, even_ld(kq));
         gemm<T>(c, 1, tm, vm.sub(0, std::min(kq, m), 0, k).t(), 0, w2);
         fill_identity(c, qw);
         gemm<T>(c, -1, vm, w2, 1, qw);

@@ -228,10 +228,10 @@ void tsqr_cholqr2(rc_context *c, Mat<T> y, Mat<T> q, Mat<T> r, int *flag) {
     const int64_t m = y.rows, n = y.cols;
     ProfScope ps(c, "op:cholqr2 %lldx%lld", (long long)m, (long long)n);
     ArenaMark mark(c);
-    Mat<T> g = rowmajor(c->alloc<T>((size_t)n * n), n, n, n);
-    Mat<T> r1 = rowmajor(c->alloc<T>((size_t)n * n), n, n, n), r1i = rowmajor(c->alloc<T>((size_t)n * n), n, n, n);
-    Mat<T> r2 = rowmajor(c->alloc<T>((size_t)n * n), n, n, n), r2i = rowmajor(c->alloc<T>((size_t)n * n), n, n, n);
-    Mat<T> q1 = rowmajor(c->alloc<T>((size_t)m * n), m, n, n);  // row-major: coalesced GEMM epilogues
+    Mat<T> g = rowmajor(c->alloc<T>((size_t)n * even_ld(n)), n, n, even_ld(n));
+    Mat<T> r1 = rowmajor(c->alloc<T>((size_t)n * even_ld(n)), n, n, even_ld(n)), r1i = rowmajor(c->alloc<T>((size_t)n * even_ld(n)), n, n, even_ld(n));
+    Mat<T> r2 = rowmajor(c->alloc<T>((size_t)n * even_ld(n)), n, n, even_ld(n)), r2i = rowmajor(c->alloc<T>((size_t)n * even_ld(n)), n, n, even_ld(n));
+    Mat<T> q1 = rowmajor(c->alloc<T>((size_t)m * even_ld(n)), m, n, even_ld(n));  // row-major: coalesced GEMM epilogues
     gemm<T>(c, 1, y.t(), y, 0, g);
     chol_inv<T>(c, g, r1, r1i, false, 0, flag);
     gemm<T>(c, 1, y, r1i, 0, q1);
@@ -516,13 +516,13 @@ void qrcp_tall_fast(rc_context *c, Mat<T> y, int64_t k, bool pivot, Mat<T> q, Ma
     const int64_t m = y.rows, n = y.cols;
     ProfScope ps(c, "op:qrcp_tall_fast %lldx%lld k=%lld pivot=%d", (long long)m, (long long)n, (long long)k, pivot ? 1 : 0);
     ArenaMark mark(c);
-    Mat<T> q1 = rowmajor(c->alloc<T>((size_t)m * n), m, n, n);
-    Mat<T> r1 = colmajor(c->alloc<T>((size_t)n * n), n, n, n);
+    Mat<T> q1 = rowmajor(c->alloc<T>((size_t)m * even_ld(n)), m, n, even_ld(n));
+    Mat<T> r1 = colmajor(c->alloc<T>((size_t)n * even_ld(n)), n, n, even_ld(n));
     tsqr_cholqr2<T>(c, y, q1, r1, flag);
-    Mat<T> q2 = colmajor(c->alloc<T>((size_t)n * k), n, k, n);
-    Mat<T> rr = r.empty() ? rowmajor(c->alloc<T>((size_t)k * n), k, n, n) : r;
+    Mat<T> q2 = colmajor(c->alloc<T>((size_t)even_ld(n) * k), n, k, even_ld(n));
+    Mat<T> rr = r.empty() ? rowmajor(c->alloc<T>((size_t)k * even_ld(n)), k, n, even_ld(n)) : r;
     qrcp_small<T>(c, r1, k, pivot, ind, rr, q2);
-    Mat<T> qq = q.empty() ? rowmajor(c->alloc<T>((size_t)m * k), m, k, k) : q;
+    Mat<T> qq = q.empty() ? rowmajor(c->alloc<T>((size_t)m * even_ld(k)), m, k, even_ld(k)) : q;
     gemm<T>(c, 1, q1, q2, 0, qq);
     householder_sign_fix<T>(c, qq, rr);
 }

@@ -155,12 +155,12 @@ void read_back(rc_context *c, const T *dev, T *host, size_t n) {
 
 template <typename T>
 Mat<T> tmp_colmajor(rc_context *c, int64_t rows, int64_t cols) {
-    int64_t ld = std::max<int64_t>(rows, 1);
+    int64_t ld = even_ld(std::max<int64_t>(rows, 1));
     return colmajor(c->alloc<T>((size_t)ld * std::max<int64_t>(cols, 1)), rows, cols, ld);
 }
 template <typename T>
 Mat<T> tmp_rowmajor(rc_context *c, int64_t rows, int64_t cols) {
-    int64_t ld = std::max<int64_t>(cols, 1);
+    int64_t ld = even_ld(std::max<int64_t>(cols, 1));
     return rowmajor(c->alloc<T>((size_t)ld * std::max<int64_t>(rows, 1)), rows, cols, ld);
 }
 

@@ -38,6 +38,9 @@ template <typename T>
 inline Mat<T> from_c(const rc_matrix &m) {
     return Mat<T>(static_cast<T *>(m.data), m.rows, m.cols, m.row_stride, m.col_stride);
 }
+// leading dimensions of internal temporaries are kept even so the GEMM can stage them with
+// 2-element vector loads
+inline int64_t even_ld(int64_t x) { return (x + 1) & ~int64_t(1); }
 // freshly allocated column-major / row-major views
 template <typename T>
 inline Mat<T> colmajor(T *p, int64_t rows, int64_t cols, int64_t ld) { return Mat<T>(p, rows, cols, 1, ld); }
