@@ -1,0 +1,84 @@
+"""CPU tests of the N > 1 path (gloo, world_size 2): the batch is sharded by matrix, each rank
+compresses its own block with no data-path collective, and ONE gather brings the packed factor
+blocks to rank 0 in global order.  The compute function is injected (here: the CPU oracle) --
+what is under test is the partition / pack / gather plumbing that bench-scale runs use over RCCL."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from rusty_compression_amd import batch
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _oracle_column_id(a, k):
+    from oracle import ref_lapack as o
+
+    cid = o.QR.compute_from(a.numpy()).compress("RANK", k).column_id()
+    return torch.from_numpy(cid.c), torch.from_numpy(cid.z), torch.from_numpy(cid.col_ind)
+
+
+def _make_batch(n_items, m, n, dtype):
+    rng = np.random.default_rng(123)
+    return [torch.from_numpy(rng.standard_normal((m, n)).astype(dtype)) for _ in range(n_items)]
+
+
+def _worker(rank, world, port, n_items, k, dtype, ret):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        mats = _make_batch(n_items, 24, 40, dtype)
+        mine = [mats[i] for i in batch.shard_range(n_items, world, rank)]
+        out = batch.batch_column_id(mine, k, compute=_oracle_column_id)
+        if rank == 0:
+            ok = len(out) == n_items
+            for i, (c, z, ind) in enumerate(out):
+                rc_, rz, rind = _oracle_column_id(mats[i], k)
+                ok = ok and torch.equal(c, rc_) and torch.equal(z, rz) and torch.equal(ind, rind)
+            ret["ok"] = bool(ok)
+        else:
+            ret[f"none{rank}"] = out is None
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_sharded_batch_gathers_in_global_order(dtype):
+    world, n_items, k = 2, 6, 5
+    port = _free_port()
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_worker, args=(world, port, n_items, k, dtype, ret), nprocs=world, join=True)
+    assert ret.get("ok") is True and ret.get("none1") is True
+
+
+def test_shard_range_is_a_contiguous_partition():
+    for n_items in (64, 10, 3, 0):
+        for world in (1, 2, 3, 8):
+            seen = []
+            for r in range(world):
+                seen += list(batch.shard_range(n_items, world, r))
+            assert seen == list(range(n_items))
+    assert list(batch.shard_range(64, 8, 3)) == list(range(24, 32))  # 8 per GPU, matrix i -> GPU i // 8
+
+
+def test_pack_unpack_round_trip_is_exact():
+    rng = np.random.default_rng(0)
+    for dtype in (torch.float64, torch.float32):
+        fs = [(torch.from_numpy(rng.standard_normal((7, 3))).to(dtype), torch.from_numpy(rng.standard_normal((3, 10))).to(dtype),
+               torch.from_numpy(rng.permutation(10) + 2 ** 40)) for _ in range(3)]
+        got = batch.unpack_factors(batch.pack_factors(fs), 3, 7, 10, 3)
+        for (c, z, i), (c2, z2, i2) in zip(fs, got):
+            assert torch.equal(c, c2) and torch.equal(z, z2) and torch.equal(i, i2)
