@@ -27,6 +27,10 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
+# one hardware queue per in-flight compression (the HIP default of 4 serialises more streams);
+# must be set before the HIP runtime initialises
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
+
 F64_MFMA_PEAK_TFLOPS = 78.6   # MI355X f64 matrix peak (vendor datasheet value)
 HBM_PEAK_GBS = 8000.0         # /opt/skills/guides/MI355X_MICROARCH.md: 8 TB/s spec (6.3 TB/s achievable)
 
@@ -54,9 +58,9 @@ def work_model(m, n, k, p, with_id=True):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=40)
-    ap.add_argument("--warmup", type=int, default=4)
-    ap.add_argument("--streams", type=int, default=4, help="independent compressions in flight per GPU")
+    ap.add_argument("--steps", type=int, default=128)
+    ap.add_argument("--warmup", type=int, default=16)
+    ap.add_argument("--streams", type=int, default=16, help="independent compressions in flight per GPU")
     ap.add_argument("--size", type=int, default=8192)
     ap.add_argument("--rank", type=int, default=128)
     ap.add_argument("--oversample", type=int, default=5)
