@@ -70,7 +70,7 @@ def agreed_pivot_prefix(ind, r, ind_ref, r_ref, dtype):
     factorizations report the same |r_jj| to the tie tolerance, i.e. each picked a column
     whose partial norm was maximal to within rounding.  f64 callers additionally assert
     that no disagreement happens inside the stable prefix at all."""
-    ns = stable_prefix(r_ref, dtype)
+    ns = min(stable_prefix(r_ref, dtype), np.asarray(r).shape[0], np.asarray(r_ref).shape[0])
     ind = np.asarray(ind)[:ns]
     ind_ref = np.asarray(ind_ref)[:ns]
     diff = np.nonzero(ind != ind_ref)[0]
