@@ -105,7 +105,10 @@ rc_status rc_graph_destroy(rc_context *ctx, void *graph_exec);
  * 0 forces the Householder chain.  While a hipGraph is being captured no fallback is
  * possible: failures are OR-ed into a health word instead, which rc_get_health returns
  * and clears (0 = every captured fast path certified itself). */
-enum { RC_OPT_TALL_SKINNY_FAST_PATH = 1 };
+/* RC_OPT_WIDE_LAZY_QRCP (default 1): pivoted QR of short-wide matrices (m <= 256 << n) keeps the
+ * m x m orthogonal factor explicitly and never rewrites the trailing matrix (same ?laqp2
+ * pivoting semantics); 0 selects the eager Householder chain. */
+enum { RC_OPT_TALL_SKINNY_FAST_PATH = 1, RC_OPT_WIDE_LAZY_QRCP = 2 };
 rc_status rc_set_option(rc_context *ctx, int32_t option, int64_t value);
 rc_status rc_get_health(rc_context *ctx, int32_t *word);
 

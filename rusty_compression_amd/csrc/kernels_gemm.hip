@@ -500,9 +500,19 @@ static bool launch_shape_f64q(rc_context *c, const GemmArgs<double> &g) {
     if (!use) return false;
     if (g.M <= 144 && g.N <= 144 && g.M > 80 && g.N > 80) launch_f64q<ALAY, BLAY, 144, 144, 16, 3, 3, VEC, 0>(c, g);
     else if (g.N <= 80) launch_f64q<ALAY, BLAY, 256, 80, 16, 8, 1, VEC, 0>(c, g);
-    else if (g.N <= 144) launch_f64q<ALAY, BLAY, 256, 144, 16, 8, 1, VEC, 0>(c, g);
+    else if (g.N <= 144) {
+        static const int v = env_int("RC_GEMM_F64Q_N", 0);
+        if (v == 1) launch_f64q<ALAY, BLAY, 128, 144, 16, 8, 1, VEC, 0>(c, g);
+        else if (v == 2) launch_f64q<ALAY, BLAY, 128, 144, 16, 4, 1, VEC, 0>(c, g);
+        else launch_f64q<ALAY, BLAY, 256, 144, 16, 8, 1, VEC, 0>(c, g);
+    }
     else if (g.M <= 80) launch_f64q<ALAY, BLAY, 80, 256, 16, 1, 8, VEC, 1>(c, g);
-    else if (g.M <= 144) launch_f64q<ALAY, BLAY, 144, 256, 16, 1, 8, VEC, 1>(c, g);
+    else if (g.M <= 144) {
+        static const int v = env_int("RC_GEMM_F64Q_M", 0);
+        if (v == 1) launch_f64q<ALAY, BLAY, 144, 128, 16, 1, 8, VEC, 1>(c, g);
+        else if (v == 2) launch_f64q<ALAY, BLAY, 144, 128, 16, 1, 4, VEC, 1>(c, g);
+        else launch_f64q<ALAY, BLAY, 144, 256, 16, 1, 8, VEC, 1>(c, g);
+    }
     else launch_f64q<ALAY, BLAY, 128, 128, 16, 2, 2, VEC, 0>(c, g);
     return true;
 }

@@ -21,6 +21,7 @@
 // serial piece per step is the single-workgroup pivot search + reflector
 // generation.
 #include "rc_common.hpp"
+#include "rc_device.hpp"
 
 namespace rc {
 
@@ -207,6 +208,67 @@ __global__ __launch_bounds__(256) void k_qr_apply(Mat<T> w, int64_t j, int pivot
     }
 }
 
+// Short columns (m - j <= 128, the k x n "wide" case, e.g. the 128 x 8192 projection B): one wave
+// owns CPW consecutive positions and handles them four at a time, so eight independent column
+// loads are in flight per lane and the reflector is read once per wave; reductions are DPP.
+template <typename T, int CPW>
+__global__ __launch_bounds__(256) void k_qr_apply_short(Mat<T> w, int64_t j, int pivot, const int64_t *jpvt, T *vn1, T *vn2, const T *tau) {
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int64_t n = w.cols, m = w.rows;
+    const int64_t p0 = j + 1 + ((int64_t)blockIdx.x * 4 + wv) * CPW;
+    if (p0 >= n) return;  // whole wave
+    const T tj = tau[j];
+    const T *vcol = w.p + jpvt[j] * w.cs;
+    const int64_t i0 = j + lane, i1 = j + lane + 64;
+    const T v0 = (i0 < m) ? ((i0 == j) ? (T)1 : vcol[i0]) : (T)0;
+    const T v1 = (i1 < m) ? vcol[i1] : (T)0;
+    for (int64_t pb = p0; pb < p0 + CPW && pb < n; pb += 4) {
+        T *xc[4];
+        T x0[4], x1[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int64_t p = pb + u;
+            xc[u] = w.p + jpvt[p < n ? p : n - 1] * w.cs;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            x0[u] = (i0 < m) ? xc[u][i0] : (T)0;
+            x1[u] = (i1 < m) ? xc[u][i1] : (T)0;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int64_t p = pb + u;
+            if (p >= n || p >= p0 + CPW) continue;  // wave-uniform
+            if (tj != (T)0) {
+                const T dot = wave_sum_dpp(fma(v0, x0[u], v1 * x1[u]));
+                const T f = tj * dot;
+                x0[u] -= f * v0;
+                x1[u] -= f * v1;
+                if (i0 < m) xc[u][i0] = x0[u];
+                if (i1 < m) xc[u][i1] = x1[u];
+            }
+            if (pivot) {
+                const T xj = read_lane(x0[u], 0);
+                const T vn = vn1[p];
+                if (vn != (T)0) {
+                    T t = fabs(xj) / vn;
+                    T temp = (T)1 - t * t;
+                    temp = temp > (T)0 ? temp : (T)0;
+                    T r = vn / vn2[p];
+                    T temp2 = temp * r * r;
+                    if (temp2 <= Num<T>::tol3z()) {
+                        T ss = (i0 > j ? x0[u] * x0[u] : (T)0) + x1[u] * x1[u];
+                        ss = wave_sum_dpp(ss);
+                        if (lane == 0) { T nn = (j < m - 1) ? sqrt(ss) : (T)0; vn1[p] = nn; vn2[p] = nn; }
+                    } else if (lane == 0) {
+                        vn1[p] = vn * sqrt(temp);
+                    }
+                }
+            }
+        }
+    }
+}
+
 // general fallback: any column length, two passes over memory (256 threads per column)
 template <typename T>
 __global__ __launch_bounds__(256) void k_qr_apply_general(Mat<T> w, int64_t j, int pivot, const int64_t *jpvt, T *vn1, T *vn2, const T *tau) {
@@ -264,7 +326,11 @@ void geqp3_inplace(rc_context *c, Mat<T> w, int64_t kmax, bool pivot, int64_t *j
 #define RC_APPLY(TPC, MAXE)                                                                                       \
     hipLaunchKernelGGL((k_qr_apply<T, TPC, MAXE>), dim3((unsigned)cdiv(rem_cols, 256 / TPC)), dim3(256), 0,      \
                        c->stream, w, j, pv, jpvt, vn1, vn2, tau)
-        if (c64 <= 2) RC_APPLY(64, 2);
+        if (c64 <= 2 && rem_cols >= 2048) {
+            constexpr int CPW = 4;
+            hipLaunchKernelGGL((k_qr_apply_short<T, CPW>), dim3((unsigned)cdiv(rem_cols, 4 * CPW)), dim3(256), 0, c->stream, w, j, pv, jpvt, vn1, vn2, tau);
+        }
+        else if (c64 <= 2) RC_APPLY(64, 2);
         else if (c64 <= 8) RC_APPLY(64, 8);
         else if (c256 <= 8) RC_APPLY(256, 8);
         else if (c256 <= 32) RC_APPLY(256, 32);
@@ -518,5 +584,293 @@ void trsm_upper(rc_context *c, Mat<T> t, Mat<T> b) {
 RC_INST(double)
 RC_INST(float)
 #undef RC_INST
+
+}  // namespace rc
+
+// ===========================================================================
+// "Lazy" pivoted QR for SHORT-WIDE matrices (m <= 256 rows, n >> m; the k x n projection B
+// of the range finder).  The trailing matrix is never updated: the m x m orthogonal factor
+// Qacc = H_0 ... H_j is kept explicitly and row j of R is produced as q_j^T B, so B is
+// READ-ONLY (it stays valid in every XCD's L2 / the Infinity Cache; the eager scheme
+// rewrote all 8 MB of it at every step and paid the cross-XCD write visibility each launch).
+//   per step: one serial workgroup (pivot search, x = Qacc^T b_p, ?larfg, Qacc <- Qacc H_j)
+//             one streaming kernel  (R[j, c] = Qacc[:, j]^T b_c, LAPACK norm down-date)
+// Same ?laqp2 semantics as the eager chain (first-max pivot, tol3z recompute with the exact
+// trailing norm); Q needs no separate ?orgqr pass.
+// ===========================================================================
+namespace rc {
+
+template <typename T>
+__global__ __launch_bounds__(256) void k_wq_init(Mat<T> qacc, Mat<T> rphys) {
+    const int64_t tq = qacc.rows * qacc.cols, tr = rphys.rows * rphys.cols;
+    for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < tq + tr; e += (int64_t)gridDim.x * blockDim.x) {
+        if (e < tq) { int64_t i = e % qacc.rows, c2 = e / qacc.rows; qacc.p[c2 * qacc.cs + i] = (i == c2) ? (T)1 : (T)0; }
+        else rphys.p[e - tq] = 0;
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(1024) void k_wq_pivot(Mat<T> b, Mat<T> qacc, Mat<T> rphys, int64_t j, int64_t *jpvt, T *vn1, T *vn2, T *tau) {
+    // The active part of Qacc (columns j..m-1) is staged in LDS for the step; 8 lanes (a DPP
+    // half row) share every dot product, so the three O(m^2) passes are ~16 FMAs per lane each.
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    const int m = (int)b.rows;
+    const int ldq = m | 1;
+    long long *shi = reinterpret_cast<long long *>(smem_raw);  // 16
+    T *shv = reinterpret_cast<T *>(shi + 16);                  // 16
+    T *Q = shv + 16;  // Q[i * ldq + r] = Qacc(r, i), i >= j only
+    T *bvec = Q + (size_t)m * ldq;
+    T *xvec = bvec + m;
+    T *vvec = xvec + m;
+    T *wvec = vvec + m;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int l8 = tid & 7, g8 = tid >> 3;  // 128 groups of 8 lanes
+    const int64_t n = b.cols;
+    const int jj = (int)j;
+    // stage Qacc[:, j:] (coalesced: rows fastest)
+    for (int e = tid; e < (m - jj) * m; e += 1024) {
+        const int i = jj + e / m, r = e % m;
+        Q[i * ldq + r] = qacc.p[(int64_t)i * qacc.cs + r];
+    }
+    {   // pivot: first maximum of vn1[j..n)
+        T best = (T)-1;
+        long long bi = 0x7fffffffffffffffLL;
+        for (int64_t p = j + tid; p < n; p += 1024) {
+            T v = fabs(vn1[p]);
+            if (v > best) { best = v; bi = p; }
+        }
+        const T mx = wave_max_dpp(best);
+        long long cand = (best == mx) ? bi : 0x7fffffffffffffffLL;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) { long long o2 = __shfl_xor(cand, off, 64); cand = o2 < cand ? o2 : cand; }
+        if (lane == 0) { shv[wv] = mx; shi[wv] = cand; }
+        __syncthreads();
+        if (tid == 0) {
+            T bb = shv[0]; long long bidx = shi[0];
+            for (int k2 = 1; k2 < 16; ++k2)
+                if (shv[k2] > bb || (shv[k2] == bb && shi[k2] < bidx)) { bb = shv[k2]; bidx = shi[k2]; }
+            const int64_t pvt = (bidx >= j && bidx < n) ? (int64_t)bidx : j;
+            if (pvt != j) {
+                int64_t t = jpvt[pvt]; jpvt[pvt] = jpvt[j]; jpvt[j] = t;
+                vn1[pvt] = vn1[j];
+                vn2[pvt] = vn2[j];
+            }
+        }
+        __syncthreads();
+    }
+    const int64_t c = jpvt[j];
+    if (tid < m) bvec[tid] = b.p[c * b.cs + tid];
+    __syncthreads();
+    // x_i = Qacc[:, i]^T b_c for i >= j  (the not yet reduced part of the pivot column)
+    for (int i = jj + g8; i < m; i += 128) {
+        T acc = 0;
+        for (int r = l8; r < m; r += 8) acc = fma(Q[i * ldq + r], bvec[r], acc);
+        acc = group_sum_dpp<8>(acc);
+        if (l8 == 0) xvec[i] = acc;
+    }
+    __syncthreads();
+    // ?larfg on x[j..m)
+    T ss = (tid > jj && tid < m) ? xvec[tid] * xvec[tid] : (T)0;
+    ss = wave_sum_dpp(ss);
+    if (lane == 0) shv[wv] = ss;
+    __syncthreads();
+    T ssq = 0;
+#pragma unroll
+    for (int k2 = 0; k2 < 16; ++k2) ssq += shv[k2];
+    const T xnorm = sqrt(ssq);
+    const T alpha = xvec[jj];
+    T tj = 0, beta = alpha;
+    if (xnorm != (T)0) {
+        beta = -copysign(hypot(alpha, xnorm), alpha);
+        tj = (beta - alpha) / beta;
+    }
+    if (tid == 0) { tau[j] = tj; rphys.p[j * rphys.rs + c] = beta; }
+    if (tj == (T)0) return;  // H_j = I: Qacc unchanged
+    const T scal = (T)1 / (alpha - beta);
+    if (tid >= jj && tid < m) vvec[tid] = (tid == jj) ? (T)1 : xvec[tid] * scal;
+    __syncthreads();
+    // w = Qacc[:, j:] v ; 8 lanes per row r
+    for (int r = g8; r < m; r += 128) {
+        T acc = 0;
+        for (int i = jj + l8; i < m; i += 8) acc = fma(Q[i * ldq + r], vvec[i], acc);
+        acc = group_sum_dpp<8>(acc);
+        if (l8 == 0) wvec[r] = tj * acc;
+    }
+    __syncthreads();
+    // Qacc[:, j:] -= (tau w) v^T, written straight back to global (coalesced: rows fastest)
+    for (int e = tid; e < (m - jj) * m; e += 1024) {
+        const int i = jj + e / m, r = e % m;
+        qacc.p[(int64_t)i * qacc.cs + r] = Q[i * ldq + r] - wvec[r] * vvec[i];
+    }
+}
+
+// R[j, c] = q_j^T b_c for every column still unpivoted + LAPACK partial-norm down-date.
+// LPC lanes per column, NE = ceil(m / LPC) rows per lane.
+template <typename T, int LPC, int NE>
+__global__ __launch_bounds__(256) void k_wq_row(Mat<T> b, Mat<T> qacc, Mat<T> rphys, int64_t j, const int64_t *jpvt, T *vn1, T *vn2) {
+    const int ll = threadIdx.x % LPC, grp = threadIdx.x / LPC;
+    const int m = (int)b.rows;
+    const int64_t n = b.cols;
+    const int64_t p = j + 1 + (int64_t)blockIdx.x * (256 / LPC) + grp;
+    const bool active = p < n;
+    const int64_t c = jpvt[active ? p : n - 1];
+    const T *qj = qacc.p + j * qacc.cs;
+    const T *bc = b.p + c * b.cs;
+    T x[NE];
+    T dot = 0;
+#pragma unroll
+    for (int e = 0; e < NE; ++e) {
+        const int i = ll + LPC * e;
+        x[e] = (i < m) ? bc[i] : (T)0;
+        dot = fma((i < m) ? qj[i] : (T)0, x[e], dot);
+    }
+    dot = group_sum_dpp<LPC>(dot);
+    if (!active) return;
+    if (ll == 0) rphys.p[j * rphys.rs + c] = dot;
+    const T vn = vn1[p];
+    if (vn != (T)0) {
+        T t = fabs(dot) / vn;
+        T temp = (T)1 - t * t;
+        temp = temp > (T)0 ? temp : (T)0;
+        T r = vn / vn2[p];
+        T temp2 = temp * r * r;
+        if (temp2 <= Num<T>::tol3z()) {
+            // exact trailing norm: || (Qacc^T b_c)[j+1:] ||
+            T ssq = 0;
+            for (int i2 = (int)j + 1; i2 < m; ++i2) {
+                const T *qi = qacc.p + (int64_t)i2 * qacc.cs;
+                T d2 = 0;
+#pragma unroll
+                for (int e = 0; e < NE; ++e) {
+                    const int i = ll + LPC * e;
+                    d2 = fma((i < m) ? qi[i] : (T)0, x[e], d2);
+                }
+                d2 = group_sum_dpp<LPC>(d2);
+                ssq = fma(d2, d2, ssq);
+            }
+            if (ll == 0) { T nn = (j < m - 1) ? sqrt(ssq) : (T)0; vn1[p] = nn; vn2[p] = nn; }
+        } else if (ll == 0) {
+            vn1[p] = vn * sqrt(temp);
+        }
+    }
+}
+
+// Vectorised variant: every lane reads its rows as 2-element vectors (16 B for f64), so one
+// 8-lane group fetches a column in 128-byte segments.  Needs even leading dimensions and
+// 2-element aligned bases (true for the library's own temporaries).
+template <typename T> struct Vec2T;
+template <> struct Vec2T<double> { typedef double type __attribute__((ext_vector_type(2))); };
+template <> struct Vec2T<float> { typedef float type __attribute__((ext_vector_type(2))); };
+
+template <typename T, int LPC, int NV>
+__global__ __launch_bounds__(256) void k_wq_row_v2(Mat<T> b, Mat<T> qacc, Mat<T> rphys, int64_t j, const int64_t *jpvt, T *vn1, T *vn2) {
+    typedef typename Vec2T<T>::type V2;
+    const int ll = threadIdx.x % LPC, grp = threadIdx.x / LPC;
+    const int m = (int)b.rows;
+    const int64_t n = b.cols;
+    const int64_t p = j + 1 + (int64_t)blockIdx.x * (256 / LPC) + grp;
+    const bool active = p < n;
+    const int64_t c = jpvt[active ? p : n - 1];
+    const T *qj = qacc.p + j * qacc.cs;
+    const T *bc = b.p + c * b.cs;
+    const T vn = vn1[active ? p : n - 1], vnb = vn2[active ? p : n - 1];  // issued early: independent of the dot product
+    V2 x[NV];
+    T dot = 0;
+#pragma unroll
+    for (int e = 0; e < NV; ++e) {
+        const int i = 2 * (ll + LPC * e);
+        V2 q2 = V2{0, 0};
+        x[e] = V2{0, 0};
+        if (i + 1 < m) { x[e] = *reinterpret_cast<const V2 *>(bc + i); q2 = *reinterpret_cast<const V2 *>(qj + i); }
+        else if (i < m) { x[e][0] = bc[i]; q2[0] = qj[i]; }
+        dot = fma(q2[0], x[e][0], dot);
+        dot = fma(q2[1], x[e][1], dot);
+    }
+    dot = group_sum_dpp<LPC>(dot);
+    if (!active) return;
+    if (ll == 0) rphys.p[j * rphys.rs + c] = dot;
+    if (vn != (T)0) {
+        T t = fabs(dot) / vn;
+        T temp = (T)1 - t * t;
+        temp = temp > (T)0 ? temp : (T)0;
+        T r = vn / vnb;
+        T temp2 = temp * r * r;
+        if (temp2 <= Num<T>::tol3z()) {
+            T ssq = 0;
+            for (int i2 = (int)j + 1; i2 < m; ++i2) {
+                const T *qi = qacc.p + (int64_t)i2 * qacc.cs;
+                T d2 = 0;
+#pragma unroll
+                for (int e = 0; e < NV; ++e) {
+                    const int i = 2 * (ll + LPC * e);
+                    if (i < m) d2 = fma(qi[i], x[e][0], d2);
+                    if (i + 1 < m) d2 = fma(qi[i + 1], x[e][1], d2);
+                }
+                d2 = group_sum_dpp<LPC>(d2);
+                ssq = fma(d2, d2, ssq);
+            }
+            if (ll == 0) { T nn = (j < m - 1) ? sqrt(ssq) : (T)0; vn1[p] = nn; vn2[p] = nn; }
+        } else if (ll == 0) {
+            vn1[p] = vn * sqrt(temp);
+        }
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void k_wq_extract(Mat<T> rphys, const int64_t *jpvt, Mat<T> r) {
+    const bool col_fast = (r.cs <= r.rs);
+    const int64_t total = r.rows * r.cols;
+    for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+        int64_t i, p;
+        if (col_fast) { i = e / r.cols; p = e - i * r.cols; }
+        else { p = e / r.rows; i = e - p * r.rows; }
+        r.at(i, p) = (i <= p) ? rphys.p[i * rphys.rs + jpvt[p]] : (T)0;
+    }
+}
+
+template <typename T>
+static size_t wq_pivot_lds(int64_t m) { return ((size_t)m * (m | 1) + 4 * (size_t)m + 16) * sizeof(T) + 16 * sizeof(long long); }
+template <typename T>
+bool wide_lazy_supported(int64_t m, int64_t n) { return m >= 2 && m <= 256 && n >= 4 * m && n >= 256 && wq_pivot_lds<T>(m) <= 160 * 1024 - 1024; }
+
+// b: m x n column-major (NOT modified); q: m x kq (any strides, may be empty); r: kmax x n (may be empty)
+template <typename T>
+void geqp3_wide_lazy(rc_context *c, Mat<T> b, int64_t kmax, int64_t *jpvt, Mat<T> q, Mat<T> r) {
+    RC_REQUIRE(b.rs == 1, RC_LAYOUT_ERROR, "geqp3_wide_lazy: column-major input required");
+    const int64_t m = b.rows, n = b.cols;
+    kmax = std::min(kmax, std::min(m, n));
+    ProfScope ps(c, "op:geqp3_wide_lazy %lldx%lld k=%lld", (long long)m, (long long)n, (long long)kmax);
+    ArenaMark mark(c);
+    T *vn = c->alloc<T>((size_t)(2 * n));
+    T *tau = c->alloc<T>((size_t)std::max<int64_t>(kmax, 1));
+    Mat<T> qacc = colmajor(c->alloc<T>((size_t)even_ld(m) * m), m, m, even_ld(m));
+    Mat<T> rphys = rowmajor(c->alloc<T>((size_t)kmax * n), kmax, n, n);
+    T *vn1 = vn, *vn2 = vn + n;
+    hipLaunchKernelGGL(k_qr_init<T>, dim3((unsigned)std::min<int64_t>(n, 65535)), dim3(256), 0, c->stream, b, 1, jpvt, vn1, vn2);
+    hipLaunchKernelGGL(k_wq_init<T>, dim3((unsigned)std::min<int64_t>(cdiv(m * m + kmax * n, 256), 4096)), dim3(256), 0, c->stream, qacc, rphys);
+    auto pk = k_wq_pivot<T>;
+    static bool attr_set[64] = {};
+    if (!attr_set[c->device & 63]) {
+        RC_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(pk), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024));
+        attr_set[c->device & 63] = true;
+    }
+    for (int64_t j = 0; j < kmax; ++j) {
+        hipLaunchKernelGGL(pk, dim3(1), dim3(1024), wq_pivot_lds<T>(m), c->stream, b, qacc, rphys, j, jpvt, vn1, vn2, tau);
+        const int64_t rem = n - j - 1;
+        if (rem <= 0) continue;
+        const bool vec_ok = (b.cs % 2) == 0 && (reinterpret_cast<uintptr_t>(b.p) % (2 * sizeof(T))) == 0;
+        if (vec_ok && m <= 128) hipLaunchKernelGGL((k_wq_row_v2<T, 8, 8>), dim3((unsigned)cdiv(rem, 32)), dim3(256), 0, c->stream, b, qacc, rphys, j, jpvt, vn1, vn2);
+        else if (m <= 64) hipLaunchKernelGGL((k_wq_row<T, 8, 8>), dim3((unsigned)cdiv(rem, 32)), dim3(256), 0, c->stream, b, qacc, rphys, j, jpvt, vn1, vn2);
+        else if (m <= 128) hipLaunchKernelGGL((k_wq_row<T, 8, 16>), dim3((unsigned)cdiv(rem, 32)), dim3(256), 0, c->stream, b, qacc, rphys, j, jpvt, vn1, vn2);
+        else hipLaunchKernelGGL((k_wq_row<T, 16, 16>), dim3((unsigned)cdiv(rem, 16)), dim3(256), 0, c->stream, b, qacc, rphys, j, jpvt, vn1, vn2);
+    }
+    if (!r.empty()) hipLaunchKernelGGL(k_wq_extract<T>, dim3((unsigned)std::min<int64_t>(cdiv(r.rows * r.cols, 256), 8192)), dim3(256), 0, c->stream, rphys, jpvt, r);
+    if (!q.empty()) copy_mat(c, qacc.sub(0, m, 0, q.cols), q);
+}
+
+template bool wide_lazy_supported<double>(int64_t, int64_t);
+template bool wide_lazy_supported<float>(int64_t, int64_t);
+template void geqp3_wide_lazy<double>(rc_context *, Mat<double>, int64_t, int64_t *, Mat<double>, Mat<double>);
+template void geqp3_wide_lazy<float>(rc_context *, Mat<float>, int64_t, int64_t *, Mat<float>, Mat<float>);
 
 }  // namespace rc

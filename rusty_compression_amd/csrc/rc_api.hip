@@ -205,6 +205,10 @@ void qrcp_core(rc_context *c, Mat<T> w, int64_t k, bool pivot, Mat<T> q, Mat<T> 
     if (c->opt_tsqr && k >= 1 && tsqr_supported<T>(w.rows, n)) {
         if (run_certified(c, [&](int *flag) { qrcp_tall_fast<T>(c, w, k, pivot, q, r, ind, flag); })) return;
     }
+    if (c->opt_wide_lazy && pivot && k >= 1 && wide_lazy_supported<T>(w.rows, n)) {
+        geqp3_wide_lazy<T>(c, w, k, ind, q, r);
+        return;
+    }
     T *tau = c->alloc<T>((size_t)std::max<int64_t>(k, 1));
     T *vn = c->alloc<T>((size_t)std::max<int64_t>(2 * n, 1));
     geqp3_inplace(c, w, k, pivot, ind, tau, vn);
@@ -750,6 +754,7 @@ rc_status rc_set_option(rc_context *ctx, int32_t option, int64_t value) {
     if (!ctx) return RC_INVALID_ARGUMENT;
     switch (option) {
         case RC_OPT_TALL_SKINNY_FAST_PATH: ctx->opt_tsqr = value != 0; return RC_OK;
+        case RC_OPT_WIDE_LAZY_QRCP: ctx->opt_wide_lazy = value != 0; return RC_OK;
         default: ctx->last_error = "unknown option"; return RC_INVALID_ARGUMENT;
     }
 }

@@ -102,6 +102,7 @@ struct rc_context {
     // fast path ORs its failure bits into; outside graph capture it is read back (one small
     // synchronisation) and the call falls back, during capture it is left for rc_get_health.
     int opt_tsqr = 1;
+    int opt_wide_lazy = 1;  // short-wide pivoted QR through the read-only lazy scheme (0: eager Householder chain)
     int *health = nullptr;
     int *health_word();
 
@@ -187,6 +188,9 @@ template <typename T> void gemm(rc_context *c, T alpha, Mat<T> a, Mat<T> b, T be
 //   tau    : kmax
 //   vn     : 2n scratch (partial norms)
 template <typename T> void geqp3_inplace(rc_context *c, Mat<T> w, int64_t kmax, bool pivot, int64_t *jpvt, T *tau, T *vn);
+// short-wide matrices (m <= 256 << n): read-only "lazy" pivoted QR with the explicit m x m factor
+template <typename T> bool wide_lazy_supported(int64_t m, int64_t n);
+template <typename T> void geqp3_wide_lazy(rc_context *c, Mat<T> b, int64_t kmax, int64_t *jpvt, Mat<T> q, Mat<T> r);
 // r(i, p) = (i <= p) ? w(i, jpvt[p]) : 0  for i < r.rows
 template <typename T> void extract_r(rc_context *c, Mat<T> w, const int64_t *jpvt, Mat<T> r);
 // qw (m x kq column-major) = H_0 ... H_{k-1} [I ; 0], reflector j stored in column jpvt[j] of w

@@ -568,3 +568,35 @@ def test_cfg5_rank64_column_id_4096_f32():
     err_ours = np.linalg.norm(an - cn @ zn) / np.linalg.norm(an)
     err_ref = np.linalg.norm(an - ocid.c @ ocid.z) / np.linalg.norm(an)
     assert abs(err_ours - err_ref) <= 2e-3 * err_ref             # same approximation quality as LAPACK's pivots
+
+
+# ---------------------------------------------------------------- short-wide pivoted QR: lazy (read-only) vs eager chain
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+@pytest.mark.parametrize("shape,smin", [((128, 8192), 1e-4), ((64, 512), 1e-5), ((33, 1000), 1e-3), ((200, 2048), 1e-6)])
+def test_wide_lazy_qrcp_matches_lapack_and_the_eager_chain(dtype, shape, smin):
+    from rusty_compression_amd import _lib
+
+    rng = np.random.default_rng(shape[0])
+    a = o.random_approximate_low_rank_matrix(shape, 1.0, smin, rng, dtype)
+    q, r, ind = o.pivoted_qr(a)
+    ctx = _lib.default_context()
+    f64 = dtype == np.float64
+    for lazy in (1, 0):
+        ctx.set_option(_lib.RC_OPT_WIDE_LAZY_QRCP, lazy)
+        try:
+            gq, gr, gi = (npy(t) for t in rc.pivoted_qr(a))
+        finally:
+            ctx.set_option(_lib.RC_OPT_WIDE_LAZY_QRCP, 1)
+        ns = agreed_pivot_prefix(gi, gr, ind, r, dtype)
+        assert is_permutation(gi, shape[1])
+        if f64:
+            assert ns == stable_prefix(r, dtype), (lazy, ns)
+            assert rel(gr[:ns], r[:ns]) <= 1e-10, (lazy, rel(gr[:ns], r[:ns]))
+        assert rel(gq @ gr, a[:, gi]) <= (1e-13 if f64 else 5e-6), lazy
+        assert np.abs(gq.T @ gq - np.eye(shape[0])).max() <= (1e-13 if f64 else 1e-5), lazy
+    # truncated factorization through the lazy path
+    gq, gr, gi = (npy(t) for t in rc.pivoted_qr(a, rank=shape[0] // 2))
+    kk = shape[0] // 2
+    if f64:
+        assert np.array_equal(gi[:kk], ind[:kk]) and rel(gq, q[:, :kk]) <= 1e-9
+        assert rel(o.apply_permutation_matrix(gr, gi, "COLINV"), o.apply_permutation_matrix(r[:kk], ind, "COLINV")) <= 1e-10
