@@ -68,6 +68,8 @@ def main():
     ap.add_argument("--no-id", action="store_true", help="rSVD only (skip QR-from-range + column ID)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-baseline-reps", type=int, default=1)
+    ap.add_argument("--profile-concurrent", action="store_true",
+                    help="diagnostic: per-stage HIP-event timers with ALL streams busy (eager launches), printed to stderr")
     args = ap.parse_args()
 
     import numpy as np
@@ -190,6 +192,35 @@ def main():
         lib.rc_profile_get(ln["ctx"]._h, i, name, 192, ctypes.byref(ms), ctypes.byref(calls))
         prof[name.value.decode()] = (ms.value, calls.value)
     lib.rc_profile_enable(ln["ctx"]._h, 0)
+
+    if args.profile_concurrent and rank == 0:
+        for l2 in lanes:
+            lib.rc_profile_enable(l2["ctx"]._h, 1)
+            lib.rc_profile_reset(l2["ctx"]._h)
+        tq0 = time.perf_counter()
+        for _ in range(4):
+            for l2 in lanes:
+                l2["call"]()
+        sync_all()
+        tq = (time.perf_counter() - tq0) / (4 * S)
+        agg = {}
+        for l2 in lanes:
+            ln_cnt = ctypes.c_int32(0)
+            l2["ctx"].check(lib.rc_profile_count(l2["ctx"]._h, ctypes.byref(ln_cnt)))
+            for i in range(ln_cnt.value):
+                name = ctypes.create_string_buffer(192)
+                ms = ctypes.c_double(0)
+                calls = ctypes.c_int64(0)
+                lib.rc_profile_get(l2["ctx"]._h, i, name, 192, ctypes.byref(ms), ctypes.byref(calls))
+                e = agg.setdefault(name.value.decode(), [0.0, 0])
+                e[0] += ms.value
+                e[1] += calls.value
+            lib.rc_profile_enable(l2["ctx"]._h, 0)
+        print("concurrent eager pass: %.3f ms/step, %d streams" % (tq * 1e3, S), file=sys.stderr)
+        for kk, (ms_, c_) in sorted(agg.items()):
+            single = prof.get(kk, (0.0, 0))
+            s_ms = single[0] / max(single[1], 1)
+            print("  %-64s %9.3f ms   (single-stream %8.3f)  x%.1f" % (kk, ms_ / max(c_, 1), s_ms, (ms_ / max(c_, 1)) / s_ms if s_ms else 0), file=sys.stderr)
 
     fl, by = work_model(m, n, k, p, with_id)
     total_flops = sum(fl.values())

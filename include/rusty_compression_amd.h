@@ -90,8 +90,11 @@ rc_status rc_memcpy_d2h(rc_context *ctx, void *dst_host, const void *src_dev, si
  * end becomes one replayable graph (launch-bound chains such as the ~130
  * dependent pivot steps of a pivoted QR replay without host launch overhead).
  * Only calls without host synchronisation may be captured, and the context must
- * have run the same call once eagerly before (workspace sizing).  No reference
- * counterpart: the reference is synchronous host code. */
+ * have run the same call once eagerly before (workspace sizing).  A graph has workspace
+ * addresses baked in: while any graph of a context is alive, a workspace the context
+ * outgrows is kept allocated instead of freed, so eager calls of any size may be mixed with
+ * replays (stream order keeps them apart).  No reference counterpart: the reference is
+ * synchronous host code. */
 rc_status rc_graph_begin_capture(rc_context *ctx);
 rc_status rc_graph_end_capture(rc_context *ctx, void **graph_exec);
 rc_status rc_graph_launch(rc_context *ctx, void *graph_exec);
@@ -108,7 +111,11 @@ rc_status rc_graph_destroy(rc_context *ctx, void *graph_exec);
 /* RC_OPT_WIDE_LAZY_QRCP (default 1): pivoted QR of short-wide matrices (m <= 256 << n) keeps the
  * m x m orthogonal factor explicitly and never rewrites the trailing matrix (same ?laqp2
  * pivoting semantics); 0 selects the eager Householder chain. */
-enum { RC_OPT_TALL_SKINNY_FAST_PATH = 1, RC_OPT_WIDE_LAZY_QRCP = 2 };
+/* RC_OPT_WIDE_COOP_QRCP (default 1): the same short-wide pivoted QR as ONE cooperative launch that
+ * keeps the whole matrix in registers (one grid barrier per Householder step instead of two kernel
+ * launches); certifies itself like the tall-skinny path (bit 4 of the health word = its workgroups
+ * could not all become resident in time) and falls back to the lazy scheme; 0 disables it. */
+enum { RC_OPT_TALL_SKINNY_FAST_PATH = 1, RC_OPT_WIDE_LAZY_QRCP = 2, RC_OPT_WIDE_COOP_QRCP = 3 };
 rc_status rc_set_option(rc_context *ctx, int32_t option, int64_t value);
 rc_status rc_get_health(rc_context *ctx, int32_t *word);
 

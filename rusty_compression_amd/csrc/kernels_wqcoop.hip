@@ -1,0 +1,476 @@
+// Register-resident cooperative pivoted QR for SHORT-WIDE matrices (m <= 256 rows, n >> m):
+// the k x n projection B = Q^H A of the range finder, reference call site
+// /root/reference/src/qr.rs:311-323 (QR::compute_from_range_estimate -> ?geqp3 of B).
+//
+// One launch factors the whole matrix.  G workgroups of 512 threads each own a slab of
+// columns and keep it in REGISTERS for the whole factorization (8 lanes per column, rows
+// interleaved: 8192 x 128 f64 = 8 MB lives in the VGPRs of 32 CUs).  Per Householder step:
+//   A  every workgroup finds its best remaining column (largest partial norm, first position
+//      on ties = idamax) and posts (norm, position, column index, the column itself) to a
+//      per-workgroup slot in global memory
+//   -- grid barrier = polling the G slot headers until all carry this step's number --
+//   B  every workgroup agrees on the pivot from the headers, fetches the winning column and
+//      redundantly generates the reflector (?larfg; identical arithmetic everywhere)
+//   C  applies it to its own columns in registers and down-dates their partial norms (?laqp2)
+// so HBM sees the matrix once on the way in and once on the way out, and the dependent chain
+// of k steps costs k grid barriers instead of 2k kernel launches.  Same ?laqp2 semantics and
+// the same in-place output format (R on/above the diagonal, reflectors below it, in the
+// physical column jpvt[j]) as the eager chain in kernels_qr.hip.
+//
+// Communication.  The 8 XCDs of the chip have private L2s, so everything that crosses workgroups
+// goes through agent-scope atomics (write-through stores / cache-bypassing loads of 8-byte words):
+// no cache write-back or invalidate fences, which would also flush the L2 contents of unrelated
+// kernels running beside this one.  A header word is valid iff its low half holds the step number;
+// a candidate column is complete before its header is written (workgroup barrier in between).
+//
+// Co-residency.  The barrier needs all G workgroups on the chip at once.  A device-wide
+// budget (semaphore, in CUs) is taken by a one-thread gate kernel launched in front, so that
+// concurrently running factorizations of other streams never demand more CUs than exist;
+// every other kernel of the library finishes without waiting on anyone, so the G workgroups
+// always become resident.  All spins are bounded: on expiry the kernel sets an abort word,
+// every workgroup leaves, the certificate flag is raised and the caller falls back to the
+// multi-kernel path (or, inside a hipGraph, reports through the health word).
+#include "rc_common.hpp"
+#include "rc_device.hpp"
+
+#include <mutex>
+
+namespace rc {
+
+namespace {
+
+constexpr int kCoopBudgetCUs = 192;      // of 256: leaves room for everything that is not cooperative
+constexpr int kCoopMaxWgs = 128;
+constexpr int kSpinLimit = 1 << 22;      // ~ seconds
+
+template <typename T> struct Tol3z;
+template <> struct Tol3z<double> { static __device__ inline double v() { return 1.0536712127723509e-08; } };
+template <> struct Tol3z<float> { static __device__ inline float v() { return 2.44140625e-04f; } };
+
+#define RC_AGENT __HIP_MEMORY_SCOPE_AGENT
+__device__ inline void st_agent(double *p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, RC_AGENT); }
+__device__ inline void st_agent(float *p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, RC_AGENT); }
+__device__ inline void st_agent(long long *p, long long v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, RC_AGENT); }
+__device__ inline void st_agent(unsigned *p, unsigned v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, RC_AGENT); }
+__device__ inline double ld_agent(const double *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, RC_AGENT); }
+__device__ inline float ld_agent(const float *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, RC_AGENT); }
+__device__ inline long long ld_agent(const long long *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, RC_AGENT); }
+__device__ inline unsigned ld_agent(const unsigned *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, RC_AGENT); }
+
+// sync words: [0] finished-workgroup counter, [1] abort (1 = run time, 2 = gate)
+// The header slots are cleared on every launch (also on every replay of a captured graph): their
+// words carry the step number they belong to, and a stale word of an earlier launch must not pass.
+__global__ void k_coop_gate(unsigned *sem, unsigned need, unsigned budget, unsigned *sync, unsigned long long *hdr, int hdr_words) {
+    if (blockIdx.x != 0) return;
+    for (int i = threadIdx.x; i < hdr_words; i += blockDim.x) __hip_atomic_store(hdr + i, 0ull, __ATOMIC_RELAXED, RC_AGENT);
+    if (threadIdx.x != 0) return;
+    st_agent(sync + 0, 0u);
+    unsigned ab = 2u;
+    for (int it = 0; it < kSpinLimit; ++it) {
+        const unsigned old = __hip_atomic_fetch_add(sem, need, __ATOMIC_RELAXED, RC_AGENT);
+        if (old + need <= budget) { ab = 0u; break; }
+        __hip_atomic_fetch_sub(sem, need, __ATOMIC_RELAXED, RC_AGENT);
+        __builtin_amdgcn_s_sleep(64);
+    }
+    st_agent(sync + 1, ab);
+}
+
+}  // namespace
+
+template <typename T>
+struct WqCoopArgs {
+    Mat<T> w;          // m x n column-major input (read once, never written)
+    Mat<T> wf;         // m x n column-major output: the factored matrix in ?geqp3 format
+    int kmax;
+    int cpw;           // columns per workgroup
+    int64_t *jpvt;     // n
+    T *tau;            // kmax
+    unsigned long long *hdr;  // [2][G][5] self-validating words (payload << 32 | step + 1): norm hi, norm lo, position, column, column at position j
+    T *cols;           // [2][G][mp]: the candidate columns
+    int mp;            // 8 * NE
+    unsigned *sync;
+    unsigned *sem;
+    int *flag;         // certificate word of run_certified (bit 4 = aborted)
+};
+
+// NE 8-row blocks per column (8 lanes per column, lane l8 holds rows l8 + 8 e), CPG columns per group.
+// Register block 0 always holds the 8-row block that contains row j: after every 8 steps the finished
+// block (final entries of R / of the reflectors) is written out and the register blocks shift down,
+// so row j sits in a register known at compile time and there is no dynamic register indexing.
+template <typename T, int NE, int CPG>
+__global__ __launch_bounds__(512) void k_wq_coop(WqCoopArgs<T> a) {
+    constexpr int NG = 64;  // 8-lane groups per workgroup (512 threads: 256 VGPRs per lane, the slab needs 128)
+    constexpr int NW = 8;
+    constexpr int kNoInt = 0x7fffffff;
+    __shared__ double sh_v[NW];
+    __shared__ int sh_p[NW], sh_c[NW], sh_j[NW];
+    __shared__ int sh_exit;
+    __shared__ int bc[4];
+    __shared__ T xw[8 * NE];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, l8 = tid & 7, g8 = tid >> 3;
+    const int m = (int)a.w.rows, mp = a.mp;
+    const int64_t n = a.w.cols;
+    const int G = gridDim.x, wg = blockIdx.x;
+    const int c0 = wg * a.cpw;
+    const int nloc = (int)((n - c0) < a.cpw ? (n - c0) : a.cpw);
+    unsigned *done = a.sync, *abortw = a.sync + 1;
+
+    const unsigned ab0 = ld_agent(abortw);
+    if (ab0 == 2u) {  // the gate gave up: no budget is held, nothing to release
+        if (tid == 0 && wg == 0) atomicOr(a.flag, 4);
+        return;
+    }
+    if (tid == 0) sh_exit = (ab0 != 0u);
+
+    // ---- load the slab into registers, initial partial norms ---------------------------
+    // lane l8 of a group owns the partial norms of the group's column q = l8 (l8 < CPG)
+    T x[CPG][NE];
+    int pos[CPG];
+    T myvn1 = 0, myvn2 = 0;
+#pragma unroll
+    for (int q = 0; q < CPG; ++q) {
+        const int cl = g8 + NG * q;
+        const bool valid = cl < nloc;
+        const T *col = a.w.p + (int64_t)(c0 + (valid ? cl : 0)) * a.w.cs;
+        T ss = 0;
+#pragma unroll
+        for (int e = 0; e < NE; ++e) {
+            const int i = l8 + 8 * e;
+            x[q][e] = (valid && i < m) ? col[i] : (T)0;
+            ss = fma(x[q][e], x[q][e], ss);
+        }
+        ss = group_sum_dpp<8>(ss);
+        if (l8 == q) myvn1 = myvn2 = sqrt(ss);
+        pos[q] = valid ? c0 + cl : -1;
+    }
+    const int mycol = c0 + g8 + NG * l8;  // meaningful for l8 < CPG
+    __syncthreads();
+    bool aborted = sh_exit != 0;
+
+    // per-phase clocks of workgroup 0 (diagnostic build only: -DRC_COOP_TIMING; costs ~100 VGPRs)
+#ifdef RC_COOP_TIMING
+    long long tph[6] = {0, 0, 0, 0, 0, 0};
+    long long tlast = clock64();
+#define RC_TICK(k) { const long long now = clock64(); tph[k] += now - tlast; tlast = now; }
+#else
+#define RC_TICK(k)
+#endif
+    int rdone = 0;  // rows below rdone have been written out
+    for (int r0 = 0; r0 < a.kmax && !aborted; r0 += 8) {
+    const int jend = r0 + 8 < a.kmax ? r0 + 8 : a.kmax;
+    for (int j = r0; j < jend && !aborted; ++j) {
+        const int par = j & 1;
+        const int lj8 = j - r0;  // row j = r0 + lj8 lives in register block 0, lane lj8
+        // ---- A: local candidate: largest partial norm, lowest position on ties (idamax) ----
+        int mypos = -1;
+#pragma unroll
+        for (int q = 0; q < CPG; ++q) mypos = (l8 == q) ? pos[q] : mypos;
+        const bool speak = l8 < CPG && mypos >= j;
+        {
+            double best = -1.0;
+            if (speak) {
+                best = fabs((double)myvn1);
+                if (!(best >= 0.0)) best = -0.5;  // NaN norms are taken last
+            }
+            const double mx = wave_max_dpp(best);
+            const int cmin = wave_min_dpp((speak && best == mx) ? mypos : kNoInt);
+            const unsigned long long mask = __ballot(speak && best == mx && mypos == cmin);
+            const unsigned long long maskj = __ballot(speak && mypos == j);
+            if (lane == 0) {
+                sh_v[wv] = mask ? mx : -1.0;
+                sh_p[wv] = cmin;
+                sh_c[wv] = -1;
+                sh_j[wv] = -1;
+            }
+            if (mask && lane == __ffsll((long long)mask) - 1) sh_c[wv] = mycol;
+            if (maskj && lane == __ffsll((long long)maskj) - 1) sh_j[wv] = mycol;
+        }
+        __syncthreads();
+        RC_TICK(0)
+        double lb = -1.0;
+        int lp = kNoInt, lc = -1, lj = -1;
+#pragma unroll
+        for (int k2 = 0; k2 < NW; ++k2) {
+            const int c2 = sh_c[k2];
+            if (c2 >= 0 && (lc < 0 || sh_v[k2] > lb || (sh_v[k2] == lb && sh_p[k2] < lp))) { lb = sh_v[k2]; lp = sh_p[k2]; lc = c2; }
+            lj = sh_j[k2] > lj ? sh_j[k2] : lj;
+        }
+        {
+            T *slot = a.cols + ((size_t)par * G + wg) * mp + r0;  // rows r0 ... of the candidate
+#pragma unroll
+            for (int q = 0; q < CPG; ++q) {
+                if (lc >= 0 && c0 + g8 + NG * q == lc) {
+#pragma unroll
+                    for (int e = 0; e < NE; ++e) {
+                        const int i = r0 + l8 + 8 * e;
+                        if (i < m) st_agent(slot + l8 + 8 * e, x[q][e]);
+                    }
+                }
+            }
+        }
+        // every store of the candidate column has completed (the barrier waits for vmcnt(0), and these are
+        // write-through stores at agent scope) before the header that announces it is written
+        __syncthreads();
+        RC_TICK(1)
+        if (wv == 0) {
+            const unsigned long long tag = (unsigned)(j + 1);
+            if (lane == 0) {
+                unsigned long long *h = a.hdr + ((size_t)par * G + wg) * 5;
+                const unsigned long long nb = (unsigned long long)__double_as_longlong(lc >= 0 ? lb : -1.0);
+                __hip_atomic_store(h + 0, (nb & 0xffffffff00000000ull) | tag, __ATOMIC_RELAXED, RC_AGENT);
+                __hip_atomic_store(h + 1, (nb << 32) | tag, __ATOMIC_RELAXED, RC_AGENT);
+                __hip_atomic_store(h + 2, ((unsigned long long)(unsigned)(lc >= 0 ? lp : kNoInt) << 32) | tag, __ATOMIC_RELAXED, RC_AGENT);
+                __hip_atomic_store(h + 3, ((unsigned long long)(unsigned)lc << 32) | tag, __ATOMIC_RELAXED, RC_AGENT);
+                __hip_atomic_store(h + 4, ((unsigned long long)(unsigned)lj << 32) | tag, __ATOMIC_RELAXED, RC_AGENT);
+            }
+            // ---- grid barrier + pivot agreement in one: poll the G headers until all carry this step's tag
+            double hb = -2.0;
+            int hp = kNoInt, hc = -1, hs = -1, hj = -1;
+            bool ab = false;
+            for (int it = 0;; ++it) {
+                bool ok = true;
+                hb = -2.0; hp = kNoInt; hc = -1; hs = -1; hj = -1;
+                for (int g = lane; g < G; g += 64) {
+                    const unsigned long long *h = a.hdr + ((size_t)par * G + g) * 5;
+                    const unsigned long long w0 = __hip_atomic_load(h + 0, __ATOMIC_RELAXED, RC_AGENT), w1 = __hip_atomic_load(h + 1, __ATOMIC_RELAXED, RC_AGENT),
+                                             w2 = __hip_atomic_load(h + 2, __ATOMIC_RELAXED, RC_AGENT), w3 = __hip_atomic_load(h + 3, __ATOMIC_RELAXED, RC_AGENT),
+                                             w4 = __hip_atomic_load(h + 4, __ATOMIC_RELAXED, RC_AGENT);
+                    ok = ok && (unsigned)w0 == (unsigned)tag && (unsigned)w1 == (unsigned)tag && (unsigned)w2 == (unsigned)tag && (unsigned)w3 == (unsigned)tag &&
+                         (unsigned)w4 == (unsigned)tag;
+                    const double nb = __longlong_as_double((long long)((w0 & 0xffffffff00000000ull) | (w1 >> 32)));
+                    const int p2 = (int)(w2 >> 32), c2 = (int)(w3 >> 32), j2 = (int)(w4 >> 32);
+                    if (c2 >= 0 && (hc < 0 || nb > hb || (nb == hb && p2 < hp))) { hb = nb; hp = p2; hc = c2; hs = g; }
+                    hj = j2 > hj ? j2 : hj;
+                }
+                if (__all(ok)) break;
+                if (it > kSpinLimit || ((it & 31) == 31 && __any(ld_agent(abortw) != 0u))) { ab = true; break; }
+                __builtin_amdgcn_s_sleep(1);
+            }
+            const double mx = wave_max_dpp(hc >= 0 ? hb : -2.0);
+            const int wp = wave_min_dpp((hc >= 0 && hb == mx) ? hp : kNoInt);
+            const unsigned long long mask = __ballot(hc >= 0 && hb == mx && hp == wp);
+            const int src = mask ? __ffsll((long long)mask) - 1 : 0;
+            const int wc = mask ? __builtin_amdgcn_readlane(hc, src) : -1;
+            const int ws = mask ? __builtin_amdgcn_readlane(hs, src) : -1;
+            const int cj = wave_max_dpp(hj);
+            if (lane == 0) {
+                if (!ab && (wc < 0 || ws < 0)) ab = true;  // cannot happen while j < n; leave cleanly instead of trusting it
+                if (ab) st_agent(abortw, 1u);
+                sh_exit = ab ? 1 : 0;
+                bc[0] = wc; bc[1] = ws; bc[2] = wp; bc[3] = cj;
+            }
+        }
+        __syncthreads();
+        RC_TICK(2)
+        if (sh_exit) { aborted = true; break; }
+        const int wcol = bc[0], wslot = bc[1], wpos = bc[2], colj = bc[3];
+        // ---- B: fetch the pivot column (complete before its header was posted); each wave then
+        //         generates the reflector redundantly (?larfg): identical arithmetic everywhere ----
+        if (tid < mp && tid >= j && tid < m) xw[tid] = ld_agent(a.cols + ((size_t)par * G + wslot) * mp + tid);
+        __syncthreads();
+        RC_TICK(3)
+        T tj = 0, beta, scal = 0;
+        {
+            T ss = 0;
+            for (int i = j + 1 + lane; i < m; i += 64) ss = fma(xw[i], xw[i], ss);
+            ss = wave_sum_dpp(ss);
+            const T xnorm = sqrt(ss);
+            const T alpha = xw[j];
+            beta = alpha;
+            if (xnorm != (T)0) {
+                // ?lapy2: w sqrt(1 + (z / w)^2) with w = max(|alpha|, xnorm)
+                const T aa = fabs(alpha);
+                const T wmax = aa > xnorm ? aa : xnorm, zmin = aa > xnorm ? xnorm : aa;
+                const T zr = zmin / wmax;
+                beta = -copysign(wmax * sqrt(fma(zr, zr, (T)1)), alpha);
+                tj = (beta - alpha) / beta;
+                scal = (T)1 / (alpha - beta);
+            }
+        }
+        if (wg == 0 && tid == 0) a.tau[j] = tj;
+        T v[NE];  // the reflector, this lane's rows r0 + l8 + 8 e: zero outside [j, m)
+#pragma unroll
+        for (int e = 0; e < NE; ++e) {
+            const int i = r0 + l8 + 8 * e;
+            v[e] = (i < j || i >= m) ? (T)0 : (i == j) ? (T)1 : xw[i] * scal;
+        }
+
+        // ---- C: bookkeeping, reflector application, norm down-date -------------------------
+        RC_TICK(4)
+        T myaj = 0;
+#pragma unroll
+        for (int q = 0; q < CPG; ++q) {
+            const int c = c0 + g8 + NG * q;
+            if (pos[q] < 0) continue;
+            if (c == wcol) {
+                // pivot column: R(j, j) = beta, the reflector goes below the diagonal (?geqp3 format)
+                pos[q] = j;
+#pragma unroll
+                for (int e = 0; e < NE; ++e) {
+                    const int i = r0 + l8 + 8 * e;
+                    if (i == j) x[q][e] = beta;
+                    else if (i > j && i < m) x[q][e] = v[e];
+                }
+                continue;
+            }
+            if (c == colj && wpos != j) pos[q] = wpos;
+            if (pos[q] <= j) continue;  // already factored
+            if (tj != (T)0) {
+                T dot = 0;
+#pragma unroll
+                for (int e = 0; e < NE; ++e) dot = fma(v[e], x[q][e], dot);
+                dot = group_sum_dpp<8>(dot);
+                const T f = tj * dot;
+#pragma unroll
+                for (int e = 0; e < NE; ++e) x[q][e] = fma(-f, v[e], x[q][e]);
+            }
+            const T aj = group_sum_dpp<8>((l8 == lj8) ? x[q][0] : (T)0);  // exactly one lane contributes
+            if (l8 == q) myaj = aj;
+        }
+        {
+            // ?laqp2 down-date by the lane that owns the column's norms; the rare exact recomputation
+            // (temp2 <= tol3z) is voted within the group and done by all 8 lanes of it
+            int np = -1;
+#pragma unroll
+            for (int q = 0; q < CPG; ++q) np = (l8 == q) ? pos[q] : np;
+            int need = 0;
+            if (l8 < CPG && np > j && myvn1 != (T)0) {
+                const T t = fabs(myaj) / myvn1;
+                T temp = (T)1 - t * t;
+                temp = temp > (T)0 ? temp : (T)0;
+                const T r = myvn1 / myvn2;
+                const T temp2 = temp * r * r;
+                if (temp2 <= Tol3z<T>::v()) need = 1 << l8;
+                else myvn1 = myvn1 * sqrt(temp);
+            }
+            need = group_sum_dpp<8>(need);
+            if (need) {
+#pragma unroll
+                for (int q = 0; q < CPG; ++q) {
+                    if (!(need & (1 << q))) continue;
+                    T ssl = 0;
+#pragma unroll
+                    for (int e = 0; e < NE; ++e) {
+                        const int i = r0 + l8 + 8 * e;
+                        if (i > j) ssl = fma(x[q][e], x[q][e], ssl);  // rows >= m hold zeros
+                    }
+                    ssl = group_sum_dpp<8>(ssl);
+                    if (l8 == q) {
+                        const T nn = (j < m - 1) ? sqrt(ssl) : (T)0;
+                        myvn1 = nn;
+                        myvn2 = nn;
+                    }
+                }
+            }
+        }
+        RC_TICK(5)
+    }
+    // ---- the 8-row block is finished: write it out, shift the register blocks down -------------
+#pragma unroll
+    for (int q = 0; q < CPG; ++q) {
+        if (!aborted && pos[q] >= 0 && r0 + l8 < m) a.wf.p[(int64_t)(c0 + g8 + NG * q) * a.wf.cs + r0 + l8] = x[q][0];
+#pragma unroll
+        for (int e = 0; e + 1 < NE; ++e) x[q][e] = x[q][e + 1];
+        x[q][NE - 1] = 0;
+    }
+    rdone = r0 + 8;
+    }
+#undef RC_TICK
+#ifdef RC_COOP_TIMING
+    if (wg == 0 && tid == 0)
+        printf("k_wq_coop wg0 clocks: A %lld  post %lld  barrier %lld  fetch %lld  select+larfg %lld  C %lld\n", tph[0], tph[1], tph[2], tph[3], tph[4], tph[5]);
+#endif
+
+    // ---- write the not yet written blocks, the permutation, and release the budget ------------
+    if (!aborted) {
+#pragma unroll
+        for (int q = 0; q < CPG; ++q) {
+            if (pos[q] < 0) continue;
+            T *col = a.wf.p + (int64_t)(c0 + g8 + NG * q) * a.wf.cs;
+#pragma unroll
+            for (int e = 0; e < NE; ++e) {
+                const int i = rdone + l8 + 8 * e;
+                if (i < m) col[i] = x[q][e];
+            }
+            if (l8 == 0) a.jpvt[pos[q]] = c0 + g8 + NG * q;
+        }
+    }
+    __syncthreads();
+    if (tid == 0) {
+        if (aborted) atomicOr(a.flag, 4);
+        const unsigned old = __hip_atomic_fetch_add(done, 1u, __ATOMIC_ACQ_REL, RC_AGENT);
+        if (old == (unsigned)G - 1u) __hip_atomic_fetch_sub(a.sem, (unsigned)G, __ATOMIC_RELAXED, RC_AGENT);
+    }
+}
+
+// ---- host side ---------------------------------------------------------------------------
+static unsigned *coop_semaphore(int device) {
+    static std::mutex mu;
+    static unsigned *sems[64] = {};
+    std::lock_guard<std::mutex> lk(mu);
+    unsigned *&s = sems[device & 63];
+    if (!s) {
+        RC_HIP(hipMalloc(reinterpret_cast<void **>(&s), 64));
+        RC_HIP(hipMemset(s, 0, 64));
+    }
+    return s;
+}
+void coop_prepare(int device) { (void)coop_semaphore(device); }
+
+template <typename T>
+static void coop_shape(int64_t m, int64_t n, int *ne, int *cpg, int *cpw, int *g) {
+    *ne = m <= 64 ? 8 : m <= 128 ? 16 : 32;
+    *cpg = m <= 64 ? 8 : m <= 128 ? 4 : 2;  // 64 matrix elements per lane
+    const int64_t cap = 64 * (int64_t)*cpg;
+    const int64_t wgs = (n + cap - 1) / cap;
+    *g = (int)wgs;
+    *cpw = (int)((n + wgs - 1) / wgs);
+}
+
+template <typename T>
+bool wide_coop_supported(int64_t m, int64_t n) {
+    if (!(m >= 2 && m <= 256 && n >= 4 * m && n >= 256)) return false;
+    int ne, cpg, cpw, g;
+    coop_shape<T>(m, n, &ne, &cpg, &cpw, &g);
+    return g >= 1 && g <= kCoopMaxWgs && n < (int64_t)1 << 30;
+}
+
+// w: m x n column-major input (left untouched); wf: m x n column-major output, the factorization in
+// the format of geqp3_inplace (R on/above the diagonal, the reflector below it in physical column
+// jpvt[j]); flag gets bit 4 when the kernel had to give up (wf, jpvt, tau are then garbage).
+template <typename T>
+void geqp3_wide_coop(rc_context *c, Mat<T> w, Mat<T> wf, int64_t kmax, int64_t *jpvt, T *tau, int *flag) {
+    RC_REQUIRE(w.rs == 1 && wf.rs == 1 && wf.rows == w.rows && wf.cols == w.cols, RC_LAYOUT_ERROR, "geqp3_wide_coop: column-major operands required");
+    const int64_t m = w.rows, n = w.cols;
+    kmax = std::min(kmax, std::min(m, n));
+    int ne, cpg, cpw, g;
+    coop_shape<T>(m, n, &ne, &cpg, &cpw, &g);
+    RC_REQUIRE(wide_coop_supported<T>(m, n), RC_INVALID_ARGUMENT, "geqp3_wide_coop: unsupported shape");
+    ProfScope ps(c, "op:geqp3_wide_coop %lldx%lld k=%lld wgs=%d", (long long)m, (long long)n, (long long)kmax, g);
+    WqCoopArgs<T> a;
+    a.w = w;
+    a.wf = wf;
+    a.kmax = (int)kmax;
+    a.cpw = cpw;
+    a.jpvt = jpvt;
+    a.tau = tau;
+    a.mp = 8 * ne;
+    a.hdr = c->alloc<unsigned long long>((size_t)2 * g * 5);
+    a.cols = c->alloc<T>((size_t)2 * g * a.mp);
+    a.sync = c->alloc<unsigned>(4);
+    a.sem = coop_semaphore(c->device);
+    a.flag = flag;
+    hipLaunchKernelGGL(k_coop_gate, dim3(1), dim3(256), 0, c->stream, a.sem, (unsigned)g, (unsigned)kCoopBudgetCUs, a.sync, a.hdr, 2 * g * 5);
+#define RC_COOP(NE_, CPG_) hipLaunchKernelGGL((k_wq_coop<T, NE_, CPG_>), dim3((unsigned)g), dim3(512), 0, c->stream, a)
+    if (ne == 8) RC_COOP(8, 8);
+    else if (ne == 16) RC_COOP(16, 4);
+    else RC_COOP(32, 2);
+#undef RC_COOP
+}
+
+template bool wide_coop_supported<double>(int64_t, int64_t);
+template bool wide_coop_supported<float>(int64_t, int64_t);
+template void geqp3_wide_coop<double>(rc_context *, Mat<double>, Mat<double>, int64_t, int64_t *, double *, int *);
+template void geqp3_wide_coop<float>(rc_context *, Mat<float>, Mat<float>, int64_t, int64_t *, float *, int *);
+
+}  // namespace rc

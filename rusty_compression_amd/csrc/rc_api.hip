@@ -15,6 +15,15 @@ using namespace rc;
 // ===========================================================================
 static constexpr size_t kAlign = 256;
 
+void rc_context::retire_arena() {
+    if (arena) {
+        if (live_graphs > 0) retired.push_back(arena);
+        else (void)hipFree(arena);
+    }
+    arena = nullptr;
+    arena_size = 0;
+}
+
 void rc_context::reset_arena() {
     if (!overflow.empty()) {
         // the previous call outgrew the arena: rebuild it once, big enough
@@ -22,9 +31,7 @@ void rc_context::reset_arena() {
         for (void *p : overflow) (void)hipFree(p);
         overflow.clear();
         size_t want = arena_high + arena_high / 4 + (1u << 20);
-        if (arena) (void)hipFree(arena);
-        arena = nullptr;
-        arena_size = 0;
+        retire_arena();
         if (hipMalloc(reinterpret_cast<void **>(&arena), want) == hipSuccess) arena_size = want;
     }
     arena_off = 0;
@@ -51,9 +58,7 @@ void *rc_context::alloc_bytes(size_t bytes) {
 void rc_context::reserve(size_t bytes) {
     if (bytes <= arena_size) return;
     RC_HIP(hipStreamSynchronize(stream));
-    if (arena) RC_HIP(hipFree(arena));
-    arena = nullptr;
-    arena_size = 0;
+    retire_arena();
     RC_HIP(hipMalloc(reinterpret_cast<void **>(&arena), bytes));
     arena_size = bytes;
 }
@@ -98,6 +103,8 @@ void rc_context::release_all() {
     prof_free.clear();
     for (void *p : overflow) (void)hipFree(p);
     overflow.clear();
+    for (void *p : retired) (void)hipFree(p);
+    retired.clear();
     if (arena) (void)hipFree(arena);
     arena = nullptr;
     arena_size = 0;
@@ -204,6 +211,23 @@ void qrcp_core(rc_context *c, Mat<T> w, int64_t k, bool pivot, Mat<T> q, Mat<T> 
     ArenaMark mark(c);
     if (c->opt_tsqr && k >= 1 && tsqr_supported<T>(w.rows, n)) {
         if (run_certified(c, [&](int *flag) { qrcp_tall_fast<T>(c, w, k, pivot, q, r, ind, flag); })) return;
+    }
+    if (c->opt_wide_coop && pivot && k >= 1 && wide_coop_supported<T>(w.rows, n)) {
+        T *tau = c->alloc<T>((size_t)k);
+        Mat<T> wf = tmp_colmajor<T>(c, w.rows, n);
+        if (run_certified(c, [&](int *flag) { geqp3_wide_coop<T>(c, w, wf, k, ind, tau, flag); })) {
+            if (!r.empty()) extract_r(c, wf, ind, r);
+            if (!q.empty()) {
+                if (q.rs == 1 && q.cs >= q.rows) {
+                    form_q(c, wf, ind, tau, k, q);
+                } else {
+                    Mat<T> qw = tmp_colmajor<T>(c, w.rows, q.cols);
+                    form_q(c, wf, ind, tau, k, qw);
+                    copy_mat(c, qw, q);
+                }
+            }
+            return;
+        }
     }
     if (c->opt_wide_lazy && pivot && k >= 1 && wide_lazy_supported<T>(w.rows, n)) {
         geqp3_wide_lazy<T>(c, w, k, ind, q, r);
@@ -634,7 +658,7 @@ rc_status rc_create(rc_context **ctx, int32_t device, void *hip_stream) {
     c->stream = static_cast<hipStream_t>(hip_stream);
     {
         DeviceGuard dg(device);
-        try { (void)c->health_word(); } catch (const Error &) { delete c; return RC_RUNTIME_ERROR; }
+        try { (void)c->health_word(); coop_prepare(device); } catch (const Error &) { delete c; return RC_RUNTIME_ERROR; }
     }
     *ctx = c;
     return RC_OK;
@@ -731,6 +755,7 @@ rc_status rc_graph_end_capture(rc_context *ctx, void **graph_exec) {
     (void)hipGraphDestroy(graph);
     if (e != hipSuccess) { ctx->last_error = std::string("hipGraphInstantiate: ") + hipGetErrorString(e); return RC_RUNTIME_ERROR; }
     *graph_exec = exec;
+    ctx->live_graphs += 1;
     return RC_OK;
 }
 rc_status rc_graph_launch(rc_context *ctx, void *graph_exec) {
@@ -746,6 +771,10 @@ rc_status rc_graph_destroy(rc_context *ctx, void *graph_exec) {
     DeviceGuard dg(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
     (void)hipGraphExecDestroy(static_cast<hipGraphExec_t>(graph_exec));
+    if (ctx->live_graphs > 0 && --ctx->live_graphs == 0) {
+        for (void *p : ctx->retired) (void)hipFree(p);
+        ctx->retired.clear();
+    }
     return RC_OK;
 }
 
@@ -755,6 +784,7 @@ rc_status rc_set_option(rc_context *ctx, int32_t option, int64_t value) {
     switch (option) {
         case RC_OPT_TALL_SKINNY_FAST_PATH: ctx->opt_tsqr = value != 0; return RC_OK;
         case RC_OPT_WIDE_LAZY_QRCP: ctx->opt_wide_lazy = value != 0; return RC_OK;
+        case RC_OPT_WIDE_COOP_QRCP: ctx->opt_wide_coop = value != 0; return RC_OK;
         default: ctx->last_error = "unknown option"; return RC_INVALID_ARGUMENT;
     }
 }

@@ -94,6 +94,11 @@ struct rc_context {
     size_t arena_off = 0;
     size_t arena_high = 0;              // high-water mark of the current call
     std::vector<void *> overflow;       // extra blocks taken while the arena was too small
+    // hipGraphs captured on this context have arena addresses baked in: while any is alive a
+    // superseded arena is retired (kept allocated) instead of freed
+    int live_graphs = 0;
+    std::vector<void *> retired;
+    void retire_arena();
     void *pinned = nullptr;             // small pinned host buffer for scalar read-backs
     size_t pinned_size = 0;
 
@@ -102,6 +107,7 @@ struct rc_context {
     // fast path ORs its failure bits into; outside graph capture it is read back (one small
     // synchronisation) and the call falls back, during capture it is left for rc_get_health.
     int opt_tsqr = 1;
+    int opt_wide_coop = 1;  // short-wide pivoted QR as ONE cooperative register-resident kernel (0: multi-kernel paths)
     int opt_wide_lazy = 1;  // short-wide pivoted QR through the read-only lazy scheme (0: eager Householder chain)
     int *health = nullptr;
     int *health_word();
@@ -191,6 +197,11 @@ template <typename T> void geqp3_inplace(rc_context *c, Mat<T> w, int64_t kmax, 
 // short-wide matrices (m <= 256 << n): read-only "lazy" pivoted QR with the explicit m x m factor
 template <typename T> bool wide_lazy_supported(int64_t m, int64_t n);
 template <typename T> void geqp3_wide_lazy(rc_context *c, Mat<T> b, int64_t kmax, int64_t *jpvt, Mat<T> q, Mat<T> r);
+// short-wide matrices, one cooperative launch (kernels_wqcoop.hip): wf gets the ?geqp3 output format;
+// flag gets bit 4 (w is never written) when the workgroups could not all become resident in time
+template <typename T> bool wide_coop_supported(int64_t m, int64_t n);
+template <typename T> void geqp3_wide_coop(rc_context *c, Mat<T> w, Mat<T> wf, int64_t kmax, int64_t *jpvt, T *tau, int *flag);
+void coop_prepare(int device);
 // r(i, p) = (i <= p) ? w(i, jpvt[p]) : 0  for i < r.rows
 template <typename T> void extract_r(rc_context *c, Mat<T> w, const int64_t *jpvt, Mat<T> r);
 // qw (m x kq column-major) = H_0 ... H_{k-1} [I ; 0], reflector j stored in column jpvt[j] of w

@@ -1,0 +1,79 @@
+// The two programs under the reference's examples/ (interpolative_decomposition.rs,
+// adaptive_sampling.rs -- minus the plot) plus a randomized SVD, written against the C++ mirror
+// include/rusty_compression.hpp.  Prints one "name value" line per check and exits non-zero when a
+// bound is violated; tests/test_gpu_parity.py builds and runs it on the GPU box, the CPU suite only
+// compiles and links it.
+#include <cstdio>
+#include <cstdlib>
+
+#include "rusty_compression.hpp"
+
+using namespace rusty_compression;
+
+static int failures = 0;
+static void expect(const char *name, double value, double bound) {
+    std::printf("%s %.3e (bound %.1e)%s\n", name, value, bound, value <= bound ? "" : "  FAILED");
+    if (!(value <= bound)) ++failures;
+}
+
+template <typename T>
+static void run(double tol_scale) {
+    Context ctx(0);
+
+    // examples/interpolative_decomposition.rs:14-44
+    {
+        const int64_t k = 20;
+        auto mat = random_approximate_low_rank_matrix<T>(ctx, 500, 100, 1.0, 1E-10, 7);
+        auto qr = QR<T>::compute_from(mat);
+        auto qr_compressed = qr.compress(CompressionType::RANK(k));
+        auto col_int_decomp = qr_compressed.column_id();
+        auto two_sided = col_int_decomp.two_sided_id();
+        expect("full_qr_reconstruction", rel_diff_fro(qr.to_mat(), mat), 1e-12 * tol_scale);
+        expect("column_id_rank20", rel_diff_fro(col_int_decomp.to_mat(), mat), 1e-1);
+        expect("two_sided_id_rank20", rel_diff_fro(two_sided.to_mat(), mat), 1e-1);
+        if (two_sided.rank() != k) { std::printf("two_sided rank %lld != 20 FAILED\n", (long long)two_sided.rank()); ++failures; }
+        // row ID through the LQ side
+        auto row_id = LQ<T>::compute_from(mat).compress(CompressionType::RANK(k)).row_id();
+        expect("row_id_rank20", rel_diff_fro(row_id.to_mat(), mat), 1e-1);
+        // ADAPTIVE compression of the QR
+        auto qr_tol = qr.compress(CompressionType::ADAPTIVE(1E-5));
+        expect("qr_adaptive_1e-5", rel_diff_fro(qr_tol.to_mat(), mat), 1e-4);
+    }
+    // examples/adaptive_sampling.rs:13-33 and :86-100
+    {
+        const double rel_tol = 1E-5;
+        auto mat = random_approximate_low_rank_matrix<T>(ctx, 500, 200, 1.0, 1E-10, 11);
+        auto res = sample_range_adaptive(mat, rel_tol, 5, 99);
+        std::printf("adaptive rank %lld history %zu\n", (long long)res.q.ncols(), res.residuals.size());
+        auto qr = QR<T>::compute_from_range_estimate(res.q, mat);
+        expect("adaptive_range_qr", rel_diff_fro(qr.to_mat(), mat), 10 * rel_tol);
+        // randomized SVD from a fixed-rank sketch, then SVD -> QR
+        auto q = sample_range_by_rank(mat, 40, 10, 5);
+        auto svd = SVD<T>::compute_from_range_estimate(q, mat);
+        expect("rsvd_rank40", rel_diff_fro(svd.to_mat(), mat), 1e-1);
+        expect("svd_to_qr", rel_diff_fro(svd.to_qr().to_mat(), svd.to_mat()), 1e-12 * tol_scale);
+    }
+    // error behaviour: a tolerance nothing meets is CompressionError (src/qr.rs:196-199)
+    {
+        auto mat = random_gaussian<T>(ctx, 64, 32, 3);
+        bool raised = false;
+        try {
+            (void)QR<T>::compute_from(mat).compress(CompressionType::ADAPTIVE(1E-14));
+        } catch (const CompressionError &) {
+            raised = true;
+        }
+        if (!raised) { std::printf("CompressionError not raised FAILED\n"); ++failures; }
+    }
+}
+
+int main() {
+    try {
+        run<double>(1.0);
+        run<float>(1e8);
+    } catch (const std::exception &e) {
+        std::printf("exception: %s\n", e.what());
+        return 2;
+    }
+    std::printf(failures ? "FAILED %d\n" : "ALL OK\n", failures);
+    return failures ? 1 : 0;
+}

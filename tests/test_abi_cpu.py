@@ -69,3 +69,23 @@ def test_mirror_exposes_the_reference_surface():
                          (rc.TwoSidedID, ("to_mat", "dot", "new"))):
         for m in methods:
             assert hasattr(cls, m), (cls.__name__, m)
+
+
+def build_cpp_mirror_examples(out_dir):
+    """g++ build of tests/cpp/mirror_examples.cpp against include/rusty_compression.hpp and the in-tree library."""
+    import subprocess
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(str(out_dir), "mirror_examples")
+    libdir = os.path.dirname(_lib.LIB_PATH)
+    cmd = ["g++", "-std=c++17", "-O1", "-Wall", "-Wextra", "-Werror", "-I" + os.path.join(root, "include"),
+           os.path.join(root, "tests", "cpp", "mirror_examples.cpp"), "-o", exe, "-L" + libdir, "-lrusty_compression_amd",
+           "-Wl,-rpath," + libdir, "-Wl,-rpath-link,/opt/rocm/lib"]
+    res = subprocess.run(cmd, capture_output=True, text=True, timeout=300)
+    assert res.returncode == 0, res.stderr
+    return exe
+
+
+def test_cpp_mirror_header_compiles_and_links_against_the_c_abi(tmp_path):
+    exe = build_cpp_mirror_examples(tmp_path)
+    assert os.path.exists(exe)

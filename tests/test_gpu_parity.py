@@ -570,10 +570,24 @@ def test_cfg5_rank64_column_id_4096_f32():
     assert abs(err_ours - err_ref) <= 2e-3 * err_ref             # same approximation quality as LAPACK's pivots
 
 
-# ---------------------------------------------------------------- short-wide pivoted QR: lazy (read-only) vs eager chain
+# ---------------------------------------------------------------- short-wide pivoted QR: cooperative / lazy / eager
+WIDE_MODES = {"coop": (1, 1), "lazy": (0, 1), "eager": (0, 0)}  # (RC_OPT_WIDE_COOP_QRCP, RC_OPT_WIDE_LAZY_QRCP)
+
+
+def _wide_mode(ctx, mode):
+    from rusty_compression_amd import _lib
+
+    coop, lazy = WIDE_MODES[mode]
+    ctx.set_option(_lib.RC_OPT_WIDE_COOP_QRCP, coop)
+    ctx.set_option(_lib.RC_OPT_WIDE_LAZY_QRCP, lazy)
+
+
 @pytest.mark.parametrize("dtype", [np.float64, np.float32])
-@pytest.mark.parametrize("shape,smin", [((128, 8192), 1e-4), ((64, 512), 1e-5), ((33, 1000), 1e-3), ((200, 2048), 1e-6)])
-def test_wide_lazy_qrcp_matches_lapack_and_the_eager_chain(dtype, shape, smin):
+@pytest.mark.parametrize("shape,smin", [((128, 8192), 1e-4), ((64, 512), 1e-5), ((33, 1000), 1e-3), ((200, 2048), 1e-6), ((128, 1031), 1e-5),
+                                        ((256, 3000), 1e-5), ((2, 300), 1e-1)])
+def test_wide_qrcp_paths_match_lapack_and_each_other(dtype, shape, smin):
+    """The three implementations of the short-wide pivoted QR (one cooperative register-resident launch,
+    the read-only lazy scheme, the eager Householder chain) against ?geqp3 + ?orgqr."""
     from rusty_compression_amd import _lib
 
     rng = np.random.default_rng(shape[0])
@@ -581,22 +595,145 @@ def test_wide_lazy_qrcp_matches_lapack_and_the_eager_chain(dtype, shape, smin):
     q, r, ind = o.pivoted_qr(a)
     ctx = _lib.default_context()
     f64 = dtype == np.float64
-    for lazy in (1, 0):
-        ctx.set_option(_lib.RC_OPT_WIDE_LAZY_QRCP, lazy)
+    results = {}
+    for mode in WIDE_MODES:
+        _wide_mode(ctx, mode)
         try:
             gq, gr, gi = (npy(t) for t in rc.pivoted_qr(a))
         finally:
-            ctx.set_option(_lib.RC_OPT_WIDE_LAZY_QRCP, 1)
+            _wide_mode(ctx, "coop")
+        assert ctx.get_health() == 0, mode
+        results[mode] = (gq, gr, gi)
         ns = agreed_pivot_prefix(gi, gr, ind, r, dtype)
-        assert is_permutation(gi, shape[1])
+        assert is_permutation(gi, shape[1]), mode
         if f64:
-            assert ns == stable_prefix(r, dtype), (lazy, ns)
-            assert rel(gr[:ns], r[:ns]) <= 1e-10, (lazy, rel(gr[:ns], r[:ns]))
-        assert rel(gq @ gr, a[:, gi]) <= (1e-13 if f64 else 5e-6), lazy
-        assert np.abs(gq.T @ gq - np.eye(shape[0])).max() <= (1e-13 if f64 else 1e-5), lazy
-    # truncated factorization through the lazy path
-    gq, gr, gi = (npy(t) for t in rc.pivoted_qr(a, rank=shape[0] // 2))
-    kk = shape[0] // 2
+            assert ns == stable_prefix(r, dtype), (mode, ns)
+            assert rel(gr[:ns], r[:ns]) <= 1e-10, (mode, rel(gr[:ns], r[:ns]))
+        assert rel(gq @ gr, a[:, gi]) <= (1e-13 if f64 else 5e-6), mode
+        assert np.abs(gq.T @ gq - np.eye(shape[0])).max() <= (1e-13 if f64 else 1e-5), mode
+    if f64:
+        # the cooperative kernel performs the eager chain's arithmetic (same reflector applications): same pivots throughout
+        ns = stable_prefix(r, dtype)
+        assert np.array_equal(results["coop"][2][:ns], results["eager"][2][:ns])
+        assert rel(results["coop"][1][:ns], results["eager"][1][:ns]) <= 1e-12
+    # truncated factorization
+    kk = max(shape[0] // 2, 1)
+    gq, gr, gi = (npy(t) for t in rc.pivoted_qr(a, rank=kk))
     if f64:
         assert np.array_equal(gi[:kk], ind[:kk]) and rel(gq, q[:, :kk]) <= 1e-9
         assert rel(o.apply_permutation_matrix(gr, gi, "COLINV"), o.apply_permutation_matrix(r[:kk], ind, "COLINV")) <= 1e-10
+
+
+def test_wide_coop_qrcp_ties_take_the_first_position():
+    """Equal column norms everywhere: idamax semantics = lowest position first, across workgroup boundaries."""
+    m, n = 16, 1024
+    a = np.zeros((m, n))
+    for c in range(n):
+        a[c % m, c] = 1.0  # every column has norm exactly 1; columns c and c + 16 are identical
+    q, r, ind = o.pivoted_qr(a)
+    gq, gr, gi = (npy(t) for t in rc.pivoted_qr(a))
+    assert np.array_equal(gi[:m], ind[:m])
+    assert rel(gq @ gr, a[:, gi]) <= 1e-14
+
+
+def test_wide_coop_qrcp_many_streams_in_flight():
+    """Eight streams replay captured cooperative factorizations at once: the device-wide CU budget keeps the
+    grid barriers live (health word stays 0) and every stream reproduces its eager result bit for bit."""
+    import ctypes
+
+    from rusty_compression_amd import _lib
+
+    lib = _lib.lib()
+    lanes = []
+    for s in range(8):
+        st = torch.cuda.Stream()
+        with torch.cuda.stream(st):
+            ctx = _lib.Context(torch.cuda.current_device(), st.cuda_stream)
+            g = torch.Generator(device="cpu").manual_seed(100 + s)
+            a = torch.randn(128, 8192, dtype=torch.float64, generator=g).cuda()
+            q = torch.empty(128, 128, dtype=torch.float64, device="cuda")
+            r = torch.empty(128, 8192, dtype=torch.float64, device="cuda")
+            ind = torch.empty(8192, dtype=torch.int64, device="cuda")
+            args = (_lib.mat(a), _lib.mat(q), _lib.mat(r), ctypes.c_void_p(ind.data_ptr()))
+            ctx.call("rc_pivoted_qr_f64", *args)
+            ctx.synchronize()
+            ref = (q.clone(), r.clone(), ind.clone())
+            graph = ctypes.c_void_p(None)
+            ctx.check(lib.rc_graph_begin_capture(ctx._h))
+            ctx.call("rc_pivoted_qr_f64", *args)
+            ctx.check(lib.rc_graph_end_capture(ctx._h, ctypes.byref(graph)))
+            q.zero_(); r.zero_(); ind.zero_()
+            lanes.append(dict(ctx=ctx, graph=graph, out=(q, r, ind), ref=ref, keep=(a, st)))
+    for _ in range(6):
+        for ln in lanes:
+            ln["ctx"].check(lib.rc_graph_launch(ln["ctx"]._h, ln["graph"]))
+    for ln in lanes:
+        ln["ctx"].synchronize()
+    for ln in lanes:
+        assert ln["ctx"].get_health() == 0
+        for got, want in zip(ln["out"], ln["ref"]):
+            assert torch.equal(got, want)
+        an, qn, rn, indn = npy(ln["keep"][0]), npy(ln["out"][0]), npy(ln["out"][1]), npy(ln["out"][2])
+        assert rel(qn @ rn, an[:, indn]) <= 1e-13
+        ln["ctx"].check(lib.rc_graph_destroy(ln["ctx"]._h, ln["graph"]))
+        ln["ctx"].close()
+
+
+def test_cpp_mirror_runs_the_reference_examples(tmp_path):
+    """include/rusty_compression.hpp (compiled host side over the C ABI) running the reference's two
+    example programs (examples/interpolative_decomposition.rs, examples/adaptive_sampling.rs)."""
+    import subprocess
+
+    from tests.test_abi_cpu import build_cpp_mirror_examples
+
+    exe = build_cpp_mirror_examples(tmp_path)
+    res = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    print(res.stdout)
+    assert res.returncode == 0, res.stdout + res.stderr
+    assert "ALL OK" in res.stdout
+
+
+def test_graph_replay_matches_eager_and_survives_workspace_growth():
+    """hipGraph capture of the fused pipeline (rc_graph_*): the replay reproduces the eager result bit
+    for bit, and an eager call that outgrows the workspace afterwards must not invalidate the graph
+    (the superseded arena is retired, not freed, while a graph is alive)."""
+    import ctypes
+
+    from rusty_compression_amd import _lib
+
+    lib = _lib.lib()
+    st = torch.cuda.Stream()
+    with torch.cuda.stream(st):
+        ctx = _lib.Context(torch.cuda.current_device(), st.cuda_stream)
+        g = torch.Generator(device="cpu").manual_seed(5)
+        a = torch.randn(1024, 768, dtype=torch.float64, generator=g).cuda()
+        om = torch.randn(768, 40, dtype=torch.float64, generator=g).cuda()
+        q = torch.empty(1024, 32, dtype=torch.float64, device="cuda")
+        args = (_lib.mat(a), ctypes.c_int64(32), ctypes.c_int64(8), _lib.mat(om), ctypes.c_uint64(0), _lib.mat(q))
+        ctx.call("rc_sample_range_by_rank_f64", *args)
+        ctx.synchronize()
+        q_eager = q.clone()
+        graph = ctypes.c_void_p(None)
+        ctx.check(lib.rc_graph_begin_capture(ctx._h))
+        ctx.call("rc_sample_range_by_rank_f64", *args)
+        ctx.check(lib.rc_graph_end_capture(ctx._h, ctypes.byref(graph)))
+        q.zero_()
+        ctx.check(lib.rc_graph_launch(ctx._h, graph))
+        ctx.synchronize()
+        assert torch.equal(q, q_eager)
+        # a much larger eager call on the same context: the arena is outgrown and rebuilt
+        big = torch.randn(4096, 1024, dtype=torch.float64, generator=g).cuda()
+        bq = torch.empty(4096, 1024, dtype=torch.float64, device="cuda")
+        br = torch.empty(1024, 1024, dtype=torch.float64, device="cuda")
+        bi = torch.empty(1024, dtype=torch.int64, device="cuda")
+        for _ in range(2):  # the second call rebuilds the arena the first one outgrew
+            ctx.call("rc_pivoted_qr_f64", _lib.mat(big), _lib.mat(bq), _lib.mat(br), ctypes.c_void_p(bi.data_ptr()))
+        assert rel(npy(bq) @ npy(br), npy(big)[:, npy(bi)]) < 1e-13
+        ctx.synchronize()
+        q.zero_()
+        ctx.check(lib.rc_graph_launch(ctx._h, graph))
+        ctx.synchronize()
+        assert torch.equal(q, q_eager)
+        assert ctx.get_health() == 0
+        ctx.check(lib.rc_graph_destroy(ctx._h, graph))
+        ctx.close()
