@@ -498,19 +498,24 @@ template <int ALAY, int BLAY, int VEC>
 static bool launch_shape_f64q(rc_context *c, const GemmArgs<double> &g) {
     static const int use = env_int("RC_GEMM_F64X4", 1);
     if (!use) return false;
+    // Skinny shapes: the narrow dimension is padded to the micro-tile granularity only -- 16 along the
+    // "shared" operand's side, 4 along the other (ORIENT picks which) -- so N = 133 costs 136, M = 128 costs 128.
+    // (N = 133 through ORIENT 1 / BN = 136 measured slower than BN = 144: 34 B-fragment reads per sub-step.)
+    static const int vn = env_int("RC_GEMM_F64Q_N", 3), vm = env_int("RC_GEMM_F64Q_M", 3);
     if (g.M <= 144 && g.N <= 144 && g.M > 80 && g.N > 80) launch_f64q<ALAY, BLAY, 144, 144, 16, 3, 3, VEC, 0>(c, g);
     else if (g.N <= 80) launch_f64q<ALAY, BLAY, 256, 80, 16, 8, 1, VEC, 0>(c, g);
+    else if (g.N <= 128 && vn == 3) launch_f64q<ALAY, BLAY, 256, 128, 16, 8, 1, VEC, 0>(c, g);
     else if (g.N <= 144) {
-        static const int v = env_int("RC_GEMM_F64Q_N", 0);
-        if (v == 1) launch_f64q<ALAY, BLAY, 128, 144, 16, 8, 1, VEC, 0>(c, g);
-        else if (v == 2) launch_f64q<ALAY, BLAY, 128, 144, 16, 4, 1, VEC, 0>(c, g);
+        if (vn == 1) launch_f64q<ALAY, BLAY, 128, 144, 16, 8, 1, VEC, 0>(c, g);
+        else if (vn == 2) launch_f64q<ALAY, BLAY, 128, 144, 16, 4, 1, VEC, 0>(c, g);
         else launch_f64q<ALAY, BLAY, 256, 144, 16, 8, 1, VEC, 0>(c, g);
     }
     else if (g.M <= 80) launch_f64q<ALAY, BLAY, 80, 256, 16, 1, 8, VEC, 1>(c, g);
+    else if (g.M <= 128 && vm == 3) launch_f64q<ALAY, BLAY, 128, 256, 16, 1, 8, VEC, 1>(c, g);
+    else if (g.M <= 136 && vm == 3) launch_f64q<ALAY, BLAY, 136, 256, 16, 2, 4, VEC, 0>(c, g);  // 68 x 64 wave tiles: 17 + 4 fragment reads per 68 MFMAs
     else if (g.M <= 144) {
-        static const int v = env_int("RC_GEMM_F64Q_M", 0);
-        if (v == 1) launch_f64q<ALAY, BLAY, 144, 128, 16, 1, 8, VEC, 1>(c, g);
-        else if (v == 2) launch_f64q<ALAY, BLAY, 144, 128, 16, 1, 4, VEC, 1>(c, g);
+        if (vm == 1) launch_f64q<ALAY, BLAY, 144, 128, 16, 1, 8, VEC, 1>(c, g);
+        else if (vm == 2) launch_f64q<ALAY, BLAY, 144, 128, 16, 1, 4, VEC, 1>(c, g);
         else launch_f64q<ALAY, BLAY, 144, 256, 16, 1, 8, VEC, 1>(c, g);
     }
     else launch_f64q<ALAY, BLAY, 128, 128, 16, 2, 2, VEC, 0>(c, g);
@@ -578,6 +583,16 @@ void gemm(rc_context *c, T alpha, Mat<T> a, Mat<T> b, T beta, Mat<T> cm) {
         Mat<T> pb = rowmajor(p, b.rows, b.cols, b.cols);
         copy_mat(c, b, pb);
         b = pb;
+    }
+    // f64, skinny N under a long M (the sketch Y = A Omega): run the transposed problem C^T = B^T A^T, so the
+    // narrow side becomes M, whose micro-tile granularity is 4 (N = 133 costs 136 instead of 144) and whose
+    // tile shapes measured faster; only the view descriptors change
+    static const int swap_ok = env_int("RC_GEMM_SWAP_SKINNY", 1);
+    if (sizeof(T) == 8 && swap_ok && b.cols <= 144 && a.rows > 144) {
+        const Mat<T> a2 = b.t(), b2 = a.t();
+        a = a2;
+        b = b2;
+        cm = cm.t();
     }
     GemmArgs<T> g;
     g.a = a.p; g.b = b.p; g.c = cm.p;

@@ -18,7 +18,7 @@ lib = _lib.lib()
 for _ in range(2):
     y = rc.matmat(a, om); b = rc.conj_matmat(a, q).t()
 lib.rc_profile_enable(ctx._h, 1); lib.rc_profile_reset(ctx._h)
-for _ in range(5):
+for _ in range(int(os.environ.get("REPS", "5"))):
     y = rc.matmat(a, om)
     bt = rc.dot(q.t(), a)
 cnt = ctypes.c_int32(0); lib.rc_profile_count(ctx._h, ctypes.byref(cnt))
