@@ -60,7 +60,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=256)
     ap.add_argument("--warmup", type=int, default=32)
-    ap.add_argument("--streams", type=int, default=32, help="independent compressions in flight per GPU (torch hands out 32 distinct streams)")
+    ap.add_argument("--streams", type=int, default=48, help="independent compressions in flight per GPU")
     ap.add_argument("--size", type=int, default=8192)
     ap.add_argument("--rank", type=int, default=128)
     ap.add_argument("--oversample", type=int, default=5)
@@ -101,9 +101,18 @@ def main():
     # ---- per-stream state: own matrix, own outputs, own context ------------------------
     lanes = []
     seen_streams = set()
+    hip = None
     for s in range(S):
-        st = torch.cuda.Stream()
-        assert st.cuda_stream not in seen_streams, "torch's stream pool wrapped around: use --streams <= 32"
+        if s < 32:
+            st = torch.cuda.Stream()
+        else:
+            # torch hands out 32 distinct streams per device; further lanes get their own HIP streams
+            if hip is None:
+                hip = ctypes.CDLL("libamdhip64.so")
+            raw = ctypes.c_void_p()
+            assert hip.hipStreamCreateWithFlags(ctypes.byref(raw), ctypes.c_uint(1)) == 0  # hipStreamNonBlocking
+            st = torch.cuda.ExternalStream(raw.value)
+        assert st.cuda_stream not in seen_streams, "duplicate stream handle"
         seen_streams.add(st.cuda_stream)
         with torch.cuda.stream(st):
             ctx = _lib.default_context()

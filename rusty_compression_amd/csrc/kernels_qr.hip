@@ -427,6 +427,51 @@ __global__ __launch_bounds__(256) void k_form_q_general(Mat<T> w, const int64_t 
     }
 }
 
+// short matrices (m <= 128, at most 128 columns of Q): ONE workgroup.  All k reflectors are staged in LDS
+// with one bulk load; 8 lanes per output column keep the column in registers, so the k dependent
+// reflector applications cost LDS broadcasts only -- one CU instead of one workgroup per column.
+template <typename T, int NE>
+__global__ __launch_bounds__(1024) void k_form_q_small(Mat<T> w, const int64_t *jpvt, const T *tau, int k, Mat<T> qw) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    T *V = reinterpret_cast<T *>(smem_raw);  // V[j * 8 * NE + i] = v_j(i): zero above the diagonal, one on it
+    T *tl = V + (size_t)k * 8 * NE;
+    const int m = (int)w.rows;
+    constexpr int LD = 8 * NE;
+    for (int e = threadIdx.x; e < k * LD; e += blockDim.x) {
+        const int j = e / LD, i = e - j * LD;
+        V[e] = (i < j || i >= m) ? (T)0 : (i == j) ? (T)1 : w.p[jpvt[j] * w.cs + i];
+    }
+    for (int j = threadIdx.x; j < k; j += blockDim.x) tl[j] = tau[j];
+    __syncthreads();
+    const int l8 = threadIdx.x & 7, cq = threadIdx.x >> 3;
+    if (cq >= qw.cols) return;
+    T x[NE];
+#pragma unroll
+    for (int e = 0; e < NE; ++e) x[e] = (l8 + 8 * e == cq) ? (T)1 : (T)0;
+    for (int j = cq < k - 1 ? cq : k - 1; j >= 0; --j) {
+        const T tj = tl[j];
+        if (tj == (T)0) continue;
+        const T *vj = V + (size_t)j * LD + l8;
+        T v[NE];
+        T dot = 0;
+#pragma unroll
+        for (int e = 0; e < NE; ++e) {
+            v[e] = vj[8 * e];
+            dot = fma(v[e], x[e], dot);
+        }
+        dot = group_sum_dpp<8>(dot);
+        const T f = tj * dot;
+#pragma unroll
+        for (int e = 0; e < NE; ++e) x[e] = fma(-f, v[e], x[e]);
+    }
+    T *out = qw.p + (int64_t)cq * qw.cs;
+#pragma unroll
+    for (int e = 0; e < NE; ++e) {
+        const int i = l8 + 8 * e;
+        if (i < m) out[i] = x[e];
+    }
+}
+
 // ---- compact-WY form-Q for tall matrices: Q = (I - V T V^T) [I ; 0] as three GEMMs ----
 // vm(i, j) = v_j(i): zeros above the diagonal, one on it, reflector below
 template <typename T>
@@ -505,6 +550,22 @@ void form_q(rc_context *c, Mat<T> w, const int64_t *jpvt, const T *tau, int64_t 
         gemm<T>(c, 1, tm, vm.sub(0, std::min(kq, m), 0, k).t(), 0, w2);
         fill_identity(c, qw);
         gemm<T>(c, -1, vm, w2, 1, qw);
+        return;
+    }
+    if (m <= 128 && qw.cols <= 128 && k <= 128) {
+        const unsigned threads = (unsigned)std::max<int64_t>(256, ((qw.cols * 8 + 63) / 64) * 64);
+        const int ne = m <= 64 ? 8 : 16;
+        const size_t lds = ((size_t)k * 8 * ne + (size_t)k) * sizeof(T);
+        auto k8 = k_form_q_small<T, 8>;
+        auto k16 = k_form_q_small<T, 16>;
+        static bool attr_set[64] = {};
+        if (!attr_set[c->device & 63]) {
+            RC_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k8), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024));
+            RC_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k16), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024));
+            attr_set[c->device & 63] = true;
+        }
+        if (ne == 8) hipLaunchKernelGGL(k8, dim3(1), dim3(threads), lds, c->stream, w, jpvt, tau, (int)k, qw);
+        else hipLaunchKernelGGL(k16, dim3(1), dim3(threads), lds, c->stream, w, jpvt, tau, (int)k, qw);
         return;
     }
     if (m <= 256 * 2) hipLaunchKernelGGL((k_form_q<T, 2>), dim3(grid), dim3(256), 0, c->stream, w, jpvt, tau, k, qw);

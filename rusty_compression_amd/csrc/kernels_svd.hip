@@ -179,6 +179,37 @@ __global__ __launch_bounds__(256) void k_jacobi_replay_v(int n, const Rot<T> *lo
     const int N = (n + 1) & ~1, npairs = N / 2;
     for (int j = lane; j < n; j += 64) v[j] = (j == row) ? (T)1 : (T)0;
     const int ns = *sweeps;
+    if (npairs <= 64) {
+        // one pair per lane: the log is one 64-entry line per round, fetched PF rounds ahead so that the
+        // dependent chain of rounds does not pay an L2 latency each
+        constexpr int PF = 8;
+        const int total = ns * (N - 1);
+        const bool has = lane < npairs;
+        for (int base = 0; base < total; base += PF) {
+            Rot<T> rt[PF];
+#pragma unroll
+            for (int u = 0; u < PF; ++u) {
+                rt[u].c = (T)1;
+                rt[u].s = (T)0;
+                if (has && base + u < total) rt[u] = log[(size_t)(base + u) * npairs + lane];
+            }
+#pragma unroll
+            for (int u = 0; u < PF; ++u) {
+                if (base + u < total) {
+                    if (rt[u].s != (T)0) {
+                        int p, q;
+                        rr_pair(N, (base + u) % (N - 1), lane, p, q);
+                        const T a = v[p], b = v[q];
+                        v[p] = rt[u].c * a - rt[u].s * b;
+                        v[q] = rt[u].s * a + rt[u].c * b;
+                    }
+                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                }
+            }
+        }
+        for (int j = lane; j < n; j += 64) vc.at(row, order[j]) = v[j];
+        return;
+    }
     for (int sw = 0; sw < ns; ++sw)
         for (int r = 0; r < N - 1; ++r) {
             const Rot<T> *lr = log + ((size_t)sw * (N - 1) + r) * npairs;
