@@ -345,7 +345,9 @@ __global__ __launch_bounds__(WM *WN * 64) void k_gemm_f64q(GemmArgs<double> g) {
         const T *as = smem + buf * STAGE, *bs = smem + A_ELEMS + buf * STAGE;
         // not unrolled: with all BK/4 sub-steps in flight the hoisted fragment loads (4 x 17 f64
         // registers) spill; one sub-step = (TM + TN) LDS reads feeding TM * TN MFMAs
-#pragma unroll 1
+        // (4-wave instances -- one wave per SIMD, 512 registers each -- are fully unrolled instead: the compiler
+        // then overlaps the next sub-step's fragment reads with the current MFMAs inside the one wave)
+#pragma unroll(NT == 256 ? BK / 4 : 1)
         for (int ks = 0; ks < BK / 4; ++ks) {
             T af[TM], bf[TN];
             const int kk = ks * 4 + lk;
@@ -511,8 +513,10 @@ static bool launch_shape_f64q(rc_context *c, const GemmArgs<double> &g) {
         else launch_f64q<ALAY, BLAY, 256, 144, 16, 8, 1, VEC, 0>(c, g);
     }
     else if (g.M <= 80) launch_f64q<ALAY, BLAY, 80, 256, 16, 1, 8, VEC, 1>(c, g);
-    else if (g.M <= 128 && vm == 3) launch_f64q<ALAY, BLAY, 128, 256, 16, 1, 8, VEC, 1>(c, g);
-    else if (g.M <= 136 && vm == 3) launch_f64q<ALAY, BLAY, 136, 256, 16, 2, 4, VEC, 0>(c, g);  // 68 x 64 wave tiles: 17 + 4 fragment reads per 68 MFMAs
+    else if (g.M <= 128 && (vm == 3 || vm == 5)) launch_f64q<ALAY, BLAY, 128, 256, 16, 1, 8, VEC, 1>(c, g);
+    else if (g.M <= 136 && vm == 5) launch_f64q<ALAY, BLAY, 136, 256, 16, 2, 2, VEC, 0>(c, g);
+    else if (g.M <= 128 && vm == 6) launch_f64q<ALAY, BLAY, 128, 256, 16, 1, 4, VEC, 1>(c, g);
+    else if (g.M <= 136 && (vm == 3 || vm == 6)) launch_f64q<ALAY, BLAY, 136, 256, 16, 2, 4, VEC, 0>(c, g);  // 68 x 64 wave tiles: 17 + 4 fragment reads per 68 MFMAs
     else if (g.M <= 144) {
         if (vm == 1) launch_f64q<ALAY, BLAY, 144, 128, 16, 1, 8, VEC, 1>(c, g);
         else if (vm == 2) launch_f64q<ALAY, BLAY, 144, 128, 16, 1, 4, VEC, 1>(c, g);
