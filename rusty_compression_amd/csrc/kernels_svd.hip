@@ -185,6 +185,9 @@ __global__ __launch_bounds__(256) void k_jacobi_replay_v(int n, const Rot<T> *lo
         constexpr int PF = 8;
         const int total = ns * (N - 1);
         const bool has = lane < npairs;
+        // circle-method pair of this lane, advanced round by round (no integer modulo in the chain):
+        // lane 0 pairs N - 1 with r; lane pi pairs (r + pi) mod (N - 1) with (r - pi) mod (N - 1)
+        int pr = lane % (N - 1), qr = ((N - 1) - lane % (N - 1)) % (N - 1);
         for (int base = 0; base < total; base += PF) {
             Rot<T> rt[PF];
 #pragma unroll
@@ -196,9 +199,11 @@ __global__ __launch_bounds__(256) void k_jacobi_replay_v(int n, const Rot<T> *lo
 #pragma unroll
             for (int u = 0; u < PF; ++u) {
                 if (base + u < total) {
+                    int p = lane == 0 ? N - 1 : pr, q = lane == 0 ? pr : qr;  // lane 0: pr runs through r itself
+                    if (p > q) { const int t = p; p = q; q = t; }
+                    pr = pr + 1 == N - 1 ? 0 : pr + 1;
+                    qr = qr + 1 == N - 1 ? 0 : qr + 1;
                     if (rt[u].s != (T)0) {
-                        int p, q;
-                        rr_pair(N, (base + u) % (N - 1), lane, p, q);
                         const T a = v[p], b = v[q];
                         v[p] = rt[u].c * a - rt[u].s * b;
                         v[q] = rt[u].s * a + rt[u].c * b;
