@@ -151,28 +151,34 @@ __global__ __launch_bounds__(256) void k_qr_apply(Mat<T> w, int64_t j, int pivot
     const bool active = p < n;
     if (TPC == 64 && !active) return;  // whole wave idle: no barrier is used on this path
     const T tj = tau[j];
-    const T *vcol = w.p + jpvt[j] * w.cs;
-    T *xcol = w.p + jpvt[active ? p : j] * w.cs;
+    // 32-bit element offsets from the two (wave-uniform) column bases at row j: one address register per
+    // array instead of a 64-bit pointer per element
+    const T *vj = w.p + jpvt[j] * w.cs + j;
+    T *xj_ = w.p + jpvt[active ? p : j] * w.cs + j;
+    const int mrem = (int)(m - j);
 
     T x[MAXE], v[MAXE];
     T dot = 0;
 #pragma unroll
     for (int e = 0; e < MAXE; ++e) {
-        int64_t i = j + lt + (int64_t)e * TPC;
-        x[e] = 0; v[e] = 0;
-        if (i < m) {
-            x[e] = xcol[i];
-            v[e] = (i == j) ? (T)1 : vcol[i];
-            dot += v[e] * x[e];
-        }
+        // branch-free: out-of-range lanes read row j (always valid) and are masked by a select -- per-element
+        // branches made the compiler shuffle the register arrays (thousands of moves, spills in the f32 build)
+        const int li = lt + e * TPC;
+        const bool ok = li < mrem;
+        const int lc = ok ? li : 0;
+        const T xv = xj_[lc], vv = vj[lc];
+        x[e] = ok ? xv : (T)0;
+        v[e] = ok ? (li == 0 ? (T)1 : vv) : (T)0;
+        dot = fma(v[e], x[e], dot);
     }
     if (tj != (T)0) {  // tau == 0: H = I (dlarf skips the update)
         dot = group_sum<T, TPC>(dot, sh);
         const T f = tj * dot;
 #pragma unroll
         for (int e = 0; e < MAXE; ++e) {
-            int64_t i = j + lt + (int64_t)e * TPC;
-            if (i < m) { x[e] -= f * v[e]; xcol[i] = x[e]; }
+            const int li = lt + e * TPC;
+            x[e] = fma(-f, v[e], x[e]);  // v is zero out of range
+            if (li < mrem) xj_[li] = x[e];
         }
     }
     if (!pivot) return;
@@ -197,8 +203,8 @@ __global__ __launch_bounds__(256) void k_qr_apply(Mat<T> w, int64_t j, int pivot
             T ss = 0;
 #pragma unroll
             for (int e = 0; e < MAXE; ++e) {
-                int64_t i = j + lt + (int64_t)e * TPC;
-                if (i > j && i < m) ss += x[e] * x[e];
+                const int li = lt + e * TPC;
+                if (li > 0 && li < mrem) ss += x[e] * x[e];
             }
             ss = group_sum<T, TPC>(ss, sh);
             if (lt == 0) { T nn = (j < m - 1) ? sqrt(ss) : (T)0; vn1[p] = nn; vn2[p] = nn; }
@@ -333,6 +339,7 @@ void geqp3_inplace(rc_context *c, Mat<T> w, int64_t kmax, bool pivot, int64_t *j
         else if (c64 <= 2) RC_APPLY(64, 2);
         else if (c64 <= 8) RC_APPLY(64, 8);
         else if (c256 <= 8) RC_APPLY(256, 8);
+        else if (c256 <= 16) RC_APPLY(256, 16);
         else if (c256 <= 32) RC_APPLY(256, 32);
         else
             hipLaunchKernelGGL(k_qr_apply_general<T>, dim3((unsigned)rem_cols), dim3(256), 0, c->stream, w, j, pv, jpvt, vn1, vn2, tau);
@@ -387,12 +394,12 @@ __global__ __launch_bounds__(256) void k_form_q(Mat<T> w, const int64_t *jpvt, c
         T dot = 0;
 #pragma unroll
         for (int e = 0; e < MAXE; ++e) {
-            int64_t i = tid + (int64_t)e * 256;
-            v[e] = 0;
-            if (i < m && i >= j) {
-                v[e] = (i == j) ? (T)1 : vcol[i];
-                dot += v[e] * x[e];
-            }
+            // branch-free (see k_qr_apply): masked lanes read row j and are zeroed by a select
+            const int i = tid + e * 256;
+            const bool ok = i < (int)m && i >= (int)j;
+            const T vv = vcol[ok ? i : (int)j];
+            v[e] = ok ? (i == (int)j ? (T)1 : vv) : (T)0;
+            dot = fma(v[e], x[e], dot);
         }
         dot = group_sum<T, 256>(dot, sh);
         const T f = tj * dot;
