@@ -48,6 +48,22 @@ __device__ inline void rr_pair(int N, int r, int pi, int &p, int &q) {
     if (p > q) { int t = p; p = q; q = t; }
 }
 
+// Rotation that annihilates the (p, q) entry of the Gram matrix: t = sign(zeta) / (|zeta| + sqrt(1 + zeta^2)),
+// c = 1 / sqrt(1 + t^2), s = c t.  Always evaluated in f64: with f32 parameters c^2 + s^2 - 1 has a systematic
+// sign, and the thousands of rotations a column goes through inflate the singular values (3e-5 at n = 300).
+// A huge |zeta| (tiny angle) is safe: t -> 0.
+template <typename T>
+__device__ inline void jacobi_rotation(T app, T aqq, T apq, T &c, T &s) {
+    const double zeta = ((double)aqq - (double)app) * fast_rcp(2.0 * (double)apq);
+    const double az = fabs(zeta);
+    const double w = 1.0 + az * az;
+    const double root = (az < 1e18) ? w * fast_rsqrt(w) : az;
+    const double t = copysign(fast_rcp(az + root), zeta);
+    const double cd = fast_rsqrt(1.0 + t * t);
+    c = (T)cd;
+    s = (T)(cd * t);
+}
+
 // one rotation record of the log
 template <typename T> struct Rot { T c, s; };
 
@@ -108,14 +124,7 @@ __global__ __launch_bounds__(LPP == 16 ? 1024 : 512) void k_jacobi_lds(Mat<T> g,
                     app = group_sum_dpp<LPP>(app); aqq = group_sum_dpp<LPP>(aqq); apq = group_sum_dpp<LPP>(apq);
                     // rotate iff |apq| > tol * sqrt(app * aqq)   (uniform over the LPP lanes)
                     if (apq * apq > tol2 * app * aqq) {
-                        const T zeta = (aqq - app) * fast_rcp((T)2 * apq);
-                        const T az = fabs(zeta);
-                        // t = sign(zeta) / (|zeta| + sqrt(1 + zeta^2)); a huge |zeta| (tiny angle) is safe: t -> 0
-                        const T w = (T)1 + az * az;
-                        const T root = (az < (T)1e18) ? w * fast_rsqrt(w) : az;
-                        const T t = copysign(fast_rcp(az + root), zeta);
-                        rot.c = fast_rsqrt((T)1 + t * t);
-                        rot.s = rot.c * t;
+                        jacobi_rotation(app, aqq, apq, rot.c, rot.s);
 #pragma unroll
                         for (int e = 0; e < NE; ++e) {
                             int i = ll + LPP * e;
@@ -236,89 +245,121 @@ __global__ __launch_bounds__(256) void k_jacobi_replay_v(int n, const Rot<T> *lo
 }
 
 // ---------------------------------------------------------------------------
-// fallback: everything in (L2-resident) global memory, V accumulated in place
+// Cores that do not fit the LDS of one CU: the same one-sided Jacobi with G and V in (L2-resident)
+// global memory, one LAUNCH per round of the circle-method schedule -- the N/2 pairs of a round are
+// disjoint, so one wave per pair needs no synchronisation inside the round and the whole chip works
+// on it.  state[0] = "some pair rotated in this sweep", state[1] = converged, state[2] = sweeps done.
 // ---------------------------------------------------------------------------
 template <typename T>
-__global__ __launch_bounds__(1024) void k_jacobi_global(Mat<T> g, Mat<T> v, Mat<T> uc, T *s, Mat<T> vc, int max_sweeps) {
-    __shared__ int sh_rot;
-    __shared__ T sig[1024];
-    __shared__ int order[1024];
-    const int tid = threadIdx.x;
-    const int l16 = tid & 15, grp = tid >> 4;
-    const int n = (int)g.rows;
-    const int N = (n + 1) & ~1;
-    const int npairs = N / 2;
+__global__ __launch_bounds__(256) void k_jacobi_round(Mat<T> g, Mat<T> v, int r, int *state) {
+    if (state[1]) return;
+    const int n = (int)g.rows, N = (n + 1) & ~1;
+    const int lane = threadIdx.x & 63;
+    const int pi = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (pi >= N / 2) return;
+    int p, q;
+    rr_pair(N, r, pi, p, q);
+    if (q >= n) return;  // the dummy column of an odd n
     const T tol = sqrt((T)n) * JEps<T>::eps();
-
-    for (int e = tid; e < n * n; e += 1024) {
-        int i = e % n, j = e / n;
-        v.p[(int64_t)j * v.cs + i] = (i == j) ? (T)1 : (T)0;
+    T *gp = g.p + (int64_t)p * g.cs, *gq = g.p + (int64_t)q * g.cs;
+    T app = 0, aqq = 0, apq = 0;
+    for (int i = lane; i < n; i += 64) {
+        const T a = gp[i], b = gq[i];
+        app = fma(a, a, app);
+        aqq = fma(b, b, aqq);
+        apq = fma(a, b, apq);
     }
-    __syncthreads();
-    for (int sweep = 0; sweep < max_sweeps; ++sweep) {
-        if (tid == 0) sh_rot = 0;
-        __syncthreads();
-        for (int r = 0; r < N - 1; ++r) {
-            for (int pi = grp; pi < npairs; pi += 64) {
-                int p, q;
-                rr_pair(N, r, pi, p, q);
-                if (q >= n) continue;
-                T *gp = g.p + (int64_t)p * g.cs, *gq = g.p + (int64_t)q * g.cs;
-                T app = 0, aqq = 0, apq = 0;
-                for (int i = l16; i < n; i += 16) {
-                    T a = gp[i], b = gq[i];
-                    app += a * a; aqq += b * b; apq += a * b;
-                }
-                app = dpp_row_sum(app); aqq = dpp_row_sum(aqq); apq = dpp_row_sum(apq);
-                if (apq == (T)0 || fabs(apq) <= tol * sqrt(app) * sqrt(aqq)) continue;
-                const T zeta = (aqq - app) / ((T)2 * apq);
-                const T t = copysign((T)1, zeta) / (fabs(zeta) + sqrt((T)1 + zeta * zeta));
-                const T cs = (T)1 / sqrt((T)1 + t * t), sn = cs * t;
-                for (int i = l16; i < n; i += 16) {
-                    T a = gp[i], b = gq[i];
-                    gp[i] = cs * a - sn * b;
-                    gq[i] = sn * a + cs * b;
-                }
-                T *vp = v.p + (int64_t)p * v.cs, *vq = v.p + (int64_t)q * v.cs;
-                for (int i = l16; i < n; i += 16) {
-                    T a = vp[i], b = vq[i];
-                    vp[i] = cs * a - sn * b;
-                    vq[i] = sn * a + cs * b;
-                }
-                if (l16 == 0) sh_rot = 1;
-            }
-            __syncthreads();
-        }
-        const int rotated = sh_rot;
-        __syncthreads();
-        if (!rotated) break;
+    app = wave_sum_dpp(app);
+    aqq = wave_sum_dpp(aqq);
+    apq = wave_sum_dpp(apq);
+    if (apq == (T)0 || fabs(apq) <= tol * sqrt(app) * sqrt(aqq)) return;
+    T cs, sn;
+    jacobi_rotation(app, aqq, apq, cs, sn);
+    for (int i = lane; i < n; i += 64) {
+        const T a = gp[i], b = gq[i];
+        gp[i] = cs * a - sn * b;
+        gq[i] = sn * a + cs * b;
     }
-    for (int j = grp; j < n; j += 64) {
-        const T *gj = g.p + (int64_t)j * g.cs;
-        T acc = 0;
-        for (int i = l16; i < n; i += 16) { T a = gj[i]; acc += a * a; }
-        acc = dpp_row_sum(acc);
-        if (l16 == 0) sig[j] = sqrt(acc);
+    T *vp = v.p + (int64_t)p * v.cs, *vq = v.p + (int64_t)q * v.cs;
+    for (int i = lane; i < n; i += 64) {
+        const T a = vp[i], b = vq[i];
+        vp[i] = cs * a - sn * b;
+        vq[i] = sn * a + cs * b;
     }
-    __syncthreads();
-    for (int i = tid; i < n; i += 1024) {
-        int rank = 0;
-        const T si = sig[i];
-        for (int j = 0; j < n; ++j) rank += (sig[j] > si || (sig[j] == si && j < i)) ? 1 : 0;
-        order[i] = rank;
-        s[rank] = si;
-    }
-    __syncthreads();
-    for (int j = grp; j < n; j += 64) {
-        const int dst = order[j];
+    if (lane == 0) state[0] = 1;
+}
+__global__ void k_jacobi_sweep_end(int *state) {
+    if (threadIdx.x != 0 || state[1]) return;
+    state[2] += 1;
+    if (state[0] == 0) state[1] = 1;
+    state[0] = 0;
+}
+// singular values = column norms of the rotated G; sig/order live in global memory
+template <typename T>
+__global__ __launch_bounds__(256) void k_jacobi_norms(Mat<T> g, T *sig) {
+    const int n = (int)g.rows, lane = threadIdx.x & 63;
+    const int j = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (j >= n) return;
+    const T *gj = g.p + (int64_t)j * g.cs;
+    T acc = 0;
+    for (int i = lane; i < n; i += 64) { const T a = gj[i]; acc = fma(a, a, acc); }
+    acc = wave_sum_dpp(acc);
+    if (lane == 0) sig[j] = sqrt(acc);
+}
+template <typename T>
+__global__ __launch_bounds__(256) void k_jacobi_rank(int n, const T *sig, int *order, T *s) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const T si = sig[i];
+    int rank = 0;
+    for (int j = 0; j < n; ++j) {
         const T sj = sig[j];
-        const T inv = sj > (T)0 ? (T)1 / sj : (T)0;
-        const T *gj = g.p + (int64_t)j * g.cs, *vj = v.p + (int64_t)j * v.cs;
-        for (int i = l16; i < n; i += 16) {
-            uc.at(i, dst) = gj[i] * inv;
-            vc.at(i, dst) = vj[i];
+        rank += (sj > si || (sj == si && j < i)) ? 1 : 0;
+    }
+    order[i] = rank;
+    s[rank] = si;
+}
+template <typename T>
+__global__ __launch_bounds__(256) void k_jacobi_emit(Mat<T> g, Mat<T> v, const T *sig, const int *order, Mat<T> uc, Mat<T> vc) {
+    const int n = (int)g.rows, lane = threadIdx.x & 63;
+    const int j = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (j >= n) return;
+    const int dst = order[j];
+    const T sj = sig[j];
+    const T inv = sj > (T)0 ? (T)1 / sj : (T)0;
+    const T *gj = g.p + (int64_t)j * g.cs, *vj = v.p + (int64_t)j * v.cs;
+    for (int i = lane; i < n; i += 64) {
+        uc.at(i, dst) = gj[i] * inv;
+        vc.at(i, dst) = vj[i];
+    }
+}
+
+template <typename T>
+static void jacobi_global(rc_context *c, Mat<T> g, Mat<T> v, Mat<T> uc, T *s, Mat<T> vc) {
+    const int n = (int)g.rows, N = (n + 1) & ~1;
+    ArenaMark mark(c);
+    int *state = c->alloc<int>(4);
+    T *sig = c->alloc<T>((size_t)n);
+    int *order = c->alloc<int>((size_t)n);
+    RC_HIP(hipMemsetAsync(state, 0, 4 * sizeof(int), c->stream));
+    fill_identity(c, v);
+    // outside a graph capture the convergence flag is read back after every sweep; inside one a fixed number
+    // of sweeps is recorded (converged sweeps return immediately)
+    const int max_sweeps = c->capturing ? 16 : 60;
+    const unsigned grid = (unsigned)((N / 2 + 3) / 4);
+    for (int sweep = 0; sweep < max_sweeps; ++sweep) {
+        for (int r = 0; r < N - 1; ++r) hipLaunchKernelGGL(k_jacobi_round<T>, dim3(grid), dim3(256), 0, c->stream, g, v, r, state);
+        hipLaunchKernelGGL(k_jacobi_sweep_end, dim3(1), dim3(64), 0, c->stream, state);
+        if (!c->capturing) {
+            int h[4] = {0, 0, 0, 0};
+            RC_HIP(hipMemcpyAsync(h, state, sizeof(h), hipMemcpyDeviceToHost, c->stream));
+            RC_HIP(hipStreamSynchronize(c->stream));
+            if (h[1]) break;
         }
     }
+    hipLaunchKernelGGL(k_jacobi_norms<T>, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, c->stream, g, sig);
+    hipLaunchKernelGGL(k_jacobi_rank<T>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, n, sig, order, s);
+    hipLaunchKernelGGL(k_jacobi_emit<T>, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, c->stream, g, v, sig, order, uc, vc);
 }
 
 template <typename T, int LPP, int NE>
@@ -364,8 +405,6 @@ static void launch_lds_lpp(rc_context *c, Mat<T> g, Mat<T> uc, T *s, Mat<T> vc, 
 template <typename T>
 void jacobi_svd(rc_context *c, Mat<T> g, Mat<T> vwork, Mat<T> uc, T *s, Mat<T> vc) {
     RC_REQUIRE(g.rows == g.cols && g.rs == 1 && vwork.rs == 1, RC_LAYOUT_ERROR, "jacobi_svd: square column-major core required");
-    RC_REQUIRE(g.rows <= 1024, RC_INVALID_ARGUMENT, "compute_svd: min(m, n) = %lld > 1024 is not supported by the single-workgroup Jacobi core",
-               (long long)g.rows);
     const int n = (int)g.rows;
     if (n == 0) return;
     ProfScope ps(c, "op:jacobi_svd n=%lld", (long long)g.rows);
@@ -377,7 +416,7 @@ void jacobi_svd(rc_context *c, Mat<T> g, Mat<T> vwork, Mat<T> uc, T *s, Mat<T> v
         else if (lpp == 8) launch_lds_lpp<T, 8>(c, g, uc, s, vc, lds, max_sweeps);
         else launch_lds_lpp<T, 16>(c, g, uc, s, vc, lds, max_sweeps);
     } else {
-        hipLaunchKernelGGL(k_jacobi_global<T>, dim3(1), dim3(1024), 0, c->stream, g, vwork, uc, s, vc, 60);
+        jacobi_global<T>(c, g, vwork, uc, s, vc);
     }
 }
 

@@ -228,6 +228,25 @@ def test_svd_reference_properties(dtype, shape, tol):
     assert ad.rank() == o.SVD.compute_from(a).compress("ADAPTIVE", 1e-4).rank()
 
 
+@pytest.mark.parametrize("dtype,shape", [(np.float64, (1000, 777)), (np.float32, (300, 900)), (np.float64, (1300, 1100)), (np.float64, (200, 199))])
+def test_svd_cores_beyond_the_lds_limit(dtype, shape):
+    """Cores that do not fit one CU's LDS run the round-per-launch Jacobi in global memory (any size):
+    singular values against ?gesdd, orthonormal factors, reconstruction; a random spectrum and a decaying one."""
+    f64 = dtype == np.float64
+    rng = np.random.default_rng(shape[0])
+    for a in (rng.standard_normal(shape).astype(dtype), o.random_approximate_low_rank_matrix(shape, 1.0, 1e-8 if f64 else 1e-4, rng, dtype)):
+        u, s, vt = (npy(t) for t in rc.compute_svd(a))
+        so = o.compute_svd(a)[1]
+        r = min(shape)
+        assert u.shape == (shape[0], r) and vt.shape == (r, shape[1])
+        assert np.all(s[:-1] >= s[1:])
+        assert np.abs(s - so).max() <= (1e-12 if f64 else 2e-5) * so[0]
+        assert rel((u * s) @ vt, a) <= (1e-12 if f64 else 5e-5)
+        lead = int((so > so[0] * (1e-6 if f64 else 1e-2)).sum())  # vectors of tiny singular values are not unique enough to compare
+        assert np.abs(u[:, :lead].T @ u[:, :lead] - np.eye(lead)).max() <= (1e-11 if f64 else 1e-4)
+        assert np.abs(vt[:lead] @ vt[:lead].T - np.eye(lead)).max() <= (1e-11 if f64 else 1e-4)
+
+
 # ---------------------------------------------------------------- compress / to_mat / IDs (a7-a10, a13-a16)
 @pytest.mark.parametrize("dtype,shape", [(np.float64, (100, 50)), (np.float32, (100, 50)), (np.float64, (50, 100)), (np.float32, (50, 100))])
 def test_qr_compression_and_ids_reference_properties(dtype, shape):
