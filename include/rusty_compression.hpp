@@ -52,6 +52,7 @@ class Context {
     Context &operator=(const Context &) = delete;
     rc_context *raw() const { return raw_; }
     void synchronize() const { check(rc_synchronize(raw_)); }
+    void set_option(int32_t option, int64_t value) const { check(rc_set_option(raw_, option, value)); }
     void check(rc_status st) const {
         if (st == RC_OK) return;
         const std::string msg = rc_last_error_message(raw_);
@@ -98,6 +99,7 @@ template <typename T> struct Api;
         static constexpr auto sample_range_by_rank = rc_sample_range_by_rank_##SUF;                                 \
         static constexpr auto sample_range_power_iteration = rc_sample_range_power_iteration_##SUF;                 \
         static constexpr auto sample_range_adaptive = rc_sample_range_adaptive_##SUF;                               \
+        static constexpr auto column_id_rank = rc_column_id_rank_##SUF;                                             \
     };
 RC_API(double, f64)
 RC_API(float, f32)
@@ -433,6 +435,23 @@ DeviceMatrix<T> sample_range_by_rank(const DeviceMatrix<T> &op, int64_t k, int64
     DeviceMatrix<T> q(op.ctx(), op.nrows(), kk);
     op.ctx().check(Api<T>::sample_range_by_rank(op.ctx().raw(), op.view(), k, p, rc_matrix{nullptr, 0, 0, 0, 0}, seed, q.view()));
     return q;
+}
+template <typename T>
+DeviceMatrix<T> sample_range_power_iteration(const DeviceMatrix<T> &op, int64_t k, int64_t p, int64_t it_count, uint64_t seed) {  // :131-160
+    int64_t kk = k < op.nrows() ? k : op.nrows();
+    if (k + p < kk) kk = k + p;
+    if (op.ncols() < kk) kk = op.ncols();
+    DeviceMatrix<T> q(op.ctx(), op.nrows(), kk);
+    op.ctx().check(Api<T>::sample_range_power_iteration(op.ctx().raw(), op.view(), k, p, it_count, rc_matrix{nullptr, 0, 0, 0, 0}, seed, q.view()));
+    return q;
+}
+// the unit of work of batches (examples/interpolative_decomposition.rs:25-32 in one call, truncated factorization)
+template <typename T>
+ColumnID<T> column_id_rank(const DeviceMatrix<T> &a, int64_t k) {
+    const int64_t kk = k < a.nrows() ? (k < a.ncols() ? k : a.ncols()) : (a.nrows() < a.ncols() ? a.nrows() : a.ncols());
+    ColumnID<T> out{DeviceMatrix<T>(a.ctx(), a.nrows(), kk), DeviceMatrix<T>(a.ctx(), kk, a.ncols()), DeviceIndex(a.ctx(), (std::size_t)a.ncols())};
+    a.ctx().check(Api<T>::column_id_rank(a.ctx().raw(), a.view(), kk, out.c.view(), out.z.view(), out.col_ind.data()));
+    return out;
 }
 template <typename T>
 T max_col_norm(const DeviceMatrix<T> &y) {  // :184-191

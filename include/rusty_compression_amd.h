@@ -115,7 +115,10 @@ rc_status rc_graph_destroy(rc_context *ctx, void *graph_exec);
  * keeps the whole matrix in registers (one grid barrier per Householder step instead of two kernel
  * launches); certifies itself like the tall-skinny path (bit 4 of the health word = its workgroups
  * could not all become resident in time) and falls back to the lazy scheme; 0 disables it. */
-enum { RC_OPT_TALL_SKINNY_FAST_PATH = 1, RC_OPT_WIDE_LAZY_QRCP = 2, RC_OPT_WIDE_COOP_QRCP = 3 };
+/* RC_OPT_POWER_ITERATION_FIXED (default 0): rc_sample_range_power_iteration_* performs it_count power steps
+ * (Y <- A orth(A^H orth(Y))) as the reference documents; 0 reproduces the reference's behaviour, where a shadowed
+ * loop variable leaves exactly one step (src/random_sampling.rs:145-153). */
+enum { RC_OPT_TALL_SKINNY_FAST_PATH = 1, RC_OPT_WIDE_LAZY_QRCP = 2, RC_OPT_WIDE_COOP_QRCP = 3, RC_OPT_POWER_ITERATION_FIXED = 4 };
 rc_status rc_set_option(rc_context *ctx, int32_t option, int64_t value);
 rc_status rc_get_health(rc_context *ctx, int32_t *word);
 

@@ -537,10 +537,11 @@ def sample_range_by_rank(op: np.ndarray, k: int, p: int, omega_source: OmegaSour
     return qr.q.copy()
 
 
-def sample_range_power_iteration(op, k, p, it_count, omega_source: OmegaSource, faithful: bool = False) -> np.ndarray:
+def sample_range_power_iteration(op, k, p, it_count, omega_source: OmegaSource, faithful: bool = False, fixed: bool = False) -> np.ndarray:
     """src/random_sampling.rs:131-160, including the shadowing quirk: every
     iteration restarts from the outer op_omega (:145) and only the last
-    iteration's product is kept (:150-153)."""
+    iteration's product is kept (:150-153).  fixed=True is the algorithm the
+    reference documents (the product is carried from iteration to iteration)."""
     n = op.shape[1]
     omega = omega_source((n, k + p))
     op_omega = matmat(op, omega, faithful)
@@ -549,6 +550,8 @@ def sample_range_power_iteration(op, k, p, it_count, omega_source: OmegaSource, 
         q = QR.compute_from(op_omega).q
         w = QR.compute_from(conj_matmat(op, q, faithful)).q
         inner = matmat(op, w, faithful)  # shadows, outer op_omega untouched
+        if fixed:
+            op_omega = inner
         if index == it_count - 1:
             res = inner.copy()
     return QR.compute_from(res).compress("RANK", k).q.copy()

@@ -435,14 +435,19 @@ void sample_range_power(rc_context *c, Mat<T> a, int64_t k, int64_t p, int64_t i
     } else {
         RC_REQUIRE(omega.rows == n && omega.cols == l, RC_INVALID_ARGUMENT, "sample_range_power_iteration: omega must be %lld x %lld", (long long)n, (long long)l);
     }
-    Mat<T> y0 = tmp_colmajor<T>(c, m, l);
-    gemm<T>(c, 1, a, omega, 0, y0);
-    Mat<T> q0 = orth_full(c, y0);                    // m x min(m, l)
-    Mat<T> z = tmp_colmajor<T>(c, n, q0.cols);
-    gemm<T>(c, 1, a.t(), q0, 0, z);                  // conj_matmat
-    Mat<T> wq = orth_full(c, z);                     // n x min(n, q0.cols)
-    Mat<T> y1 = tmp_colmajor<T>(c, m, wq.cols);
-    gemm<T>(c, 1, a, wq, 0, y1);
+    Mat<T> y1 = tmp_colmajor<T>(c, m, l);
+    gemm<T>(c, 1, a, omega, 0, y1);
+    // The reference's loop restarts every iteration from the first product (a shadowed variable), so exactly one
+    // power step survives; RC_OPT_POWER_ITERATION_FIXED = 1 runs the it_count steps the documentation describes.
+    const int64_t steps = c->opt_power_fixed ? it_count : 1;
+    for (int64_t it = 0; it < steps; ++it) {
+        Mat<T> q0 = orth_full(c, y1);                    // m x min(m, l)
+        Mat<T> z = tmp_colmajor<T>(c, n, q0.cols);
+        gemm<T>(c, 1, a.t(), q0, 0, z);                  // conj_matmat
+        Mat<T> wq = orth_full(c, z);                     // n x min(n, q0.cols)
+        y1 = tmp_colmajor<T>(c, m, wq.cols);
+        gemm<T>(c, 1, a, wq, 0, y1);
+    }
     const int64_t kk = std::min(k, std::min(m, y1.cols));
     RC_REQUIRE(q.rows == m && q.cols == kk, RC_INVALID_ARGUMENT, "sample_range_power_iteration: q must be %lld x %lld", (long long)m, (long long)kk);
     int64_t *ind = c->alloc<int64_t>((size_t)std::max<int64_t>(y1.cols, 1));
@@ -785,6 +790,7 @@ rc_status rc_set_option(rc_context *ctx, int32_t option, int64_t value) {
         case RC_OPT_TALL_SKINNY_FAST_PATH: ctx->opt_tsqr = value != 0; return RC_OK;
         case RC_OPT_WIDE_LAZY_QRCP: ctx->opt_wide_lazy = value != 0; return RC_OK;
         case RC_OPT_WIDE_COOP_QRCP: ctx->opt_wide_coop = value != 0; return RC_OK;
+        case RC_OPT_POWER_ITERATION_FIXED: ctx->opt_power_fixed = value != 0; return RC_OK;
         default: ctx->last_error = "unknown option"; return RC_INVALID_ARGUMENT;
     }
 }

@@ -107,6 +107,7 @@ struct rc_context {
     // fast path ORs its failure bits into; outside graph capture it is read back (one small
     // synchronisation) and the call falls back, during capture it is left for rc_get_health.
     int opt_tsqr = 1;
+    int opt_power_fixed = 0;  // 1: sample_range_power_iteration really iterates it_count times (opt-in; the reference does one)
     int opt_wide_coop = 1;  // short-wide pivoted QR as ONE cooperative register-resident kernel (0: multi-kernel paths)
     int opt_wide_lazy = 1;  // short-wide pivoted QR through the read-only lazy scheme (0: eager Householder chain)
     int *health = nullptr;

@@ -52,6 +52,9 @@ static void run(double tol_scale) {
         auto svd = SVD<T>::compute_from_range_estimate(q, mat);
         expect("rsvd_rank40", rel_diff_fro(svd.to_mat(), mat), 1e-1);
         expect("svd_to_qr", rel_diff_fro(svd.to_qr().to_mat(), svd.to_mat()), 1e-12 * tol_scale);
+        auto qp = sample_range_power_iteration(mat, 40, 10, 2, 5);
+        expect("power_iteration_range", rel_diff_fro(dot(qp, dot(transpose(qp), mat)), mat), 1e-1);
+        expect("column_id_rank40", rel_diff_fro(column_id_rank(mat, 40).to_mat(), mat), 2e-1);
     }
     // error behaviour: a tolerance nothing meets is CompressionError (src/qr.rs:196-199)
     {

@@ -362,6 +362,30 @@ def test_sketch_rsvd_and_range_qr_match_golden():
     assert rel(npy(cid.c), g["id_c"]) <= 1e-10 and rel(npy(cid.z), g["id_z"]) <= 1e-9
 
 
+def test_power_iteration_fixed_mode_is_opt_in_and_matches_the_documented_algorithm():
+    """RC_OPT_POWER_ITERATION_FIXED: it_count real power steps; the default keeps
+    the reference's shadowing quirk (one step).  Oracle: oracle/ref_lapack.sample_range_power_iteration(fixed=True)."""
+    from rusty_compression_amd import _lib
+
+    g = golden("cfg1_sketch_rsvd.npz")
+    a, omega, k, p = g["a"], g["omega"], int(g["k"]), int(g["p"])
+    ctx = _lib.default_context()
+    want = o.sample_range_power_iteration(a, k, p, 2, lambda shape: omega, fixed=True)
+    ctx.set_option(_lib.RC_OPT_POWER_ITERATION_FIXED, 1)
+    try:
+        got2 = npy(rc.sample_range_power_iteration(a, k, p, 2, omega))
+        got1 = npy(rc.sample_range_power_iteration(a, k, p, 1, omega))
+    finally:
+        ctx.set_option(_lib.RC_OPT_POWER_ITERATION_FIXED, 0)
+    assert rel(got2, want) <= 1e-9
+    assert rel(got1, g["q_power"]) <= 1e-10                     # one step: identical to the quirk
+    assert rel(got2, g["q_power"]) > 1e-6                       # two real steps are a different basis
+    # more power steps = a better range for a matrix with a decaying spectrum
+    err = lambda q: np.linalg.norm(a - q @ (q.T @ a)) / np.linalg.norm(a)
+    assert err(got2) <= err(g["q_power"]) * (1 + 1e-9)
+    assert rel(npy(rc.sample_range_power_iteration(a, k, p, 2, omega)), g["q_power"]) <= 1e-10  # option off again
+
+
 def test_fused_rsvd_id_equals_the_separate_calls():
     import ctypes
 
