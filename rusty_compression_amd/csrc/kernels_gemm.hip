@@ -278,6 +278,22 @@ __global__ __launch_bounds__(WM *WN * 64) void k_gemm_mfma(GemmArgs<T> g) {
 // so all 64 result lanes are distinct outputs, rows of C are written in 128-byte segments
 // (ORIENT 0) and the LDS images / pitches are exactly those of the 16x16x4 kernel.
 // ---------------------------------------------------------------------------
+#ifdef RC_GEMM_TIMING
+// diagnostic build (tools/gemm_timing.py): wave 0 of workgroup (0, 0) accumulates s_memtime deltas per phase of the main loop
+__device__ unsigned long long g_gemm_dbg[8];
+#define RC_STAMP(k)                                                                              \
+    {                                                                                            \
+        unsigned long long now_;                                                                 \
+        __builtin_amdgcn_sched_barrier(0);                                                       \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(now_)::"memory");           \
+        __builtin_amdgcn_sched_barrier(0);                                                       \
+        tacc[k] += now_ - tlast;                                                                 \
+        tlast = now_;                                                                            \
+    }
+#else
+#define RC_STAMP(k)
+#endif
+
 template <int ALAY, int BLAY, int BM, int BN, int BK, int WM, int WN, int VEC, int ORIENT>
 __global__ __launch_bounds__(WM *WN * 64) void k_gemm_f64q(GemmArgs<double> g) {
     typedef double T;
@@ -335,6 +351,10 @@ __global__ __launch_bounds__(WM *WN * 64) void k_gemm_f64q(GemmArgs<double> g) {
     }
     __syncthreads();
     constexpr int AM = ORIENT == 0 ? 4 : 16, BNW = ORIENT == 0 ? 16 : 4;
+#ifdef RC_GEMM_TIMING
+    unsigned long long tacc[5] = {0, 0, 0, 0, 0}, tlast;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tlast)::"memory");
+#endif
     for (int64_t it = 0; it < nk; ++it) {
         const int buf = (int)(it & 1);
         if (it + 1 < nk) {
@@ -342,6 +362,7 @@ __global__ __launch_bounds__(WM *WN * 64) void k_gemm_f64q(GemmArgs<double> g) {
             sa.load(m0, g.M, kbeg + koff, kend, koff * g.sak, g.sam, g.sak, tid);
             sb.load(n0, g.N, kbeg + koff, kend, koff * g.sbk, g.sbn, g.sbk, tid);
         }
+        RC_STAMP(0)
         const T *as = smem + buf * STAGE, *bs = smem + A_ELEMS + buf * STAGE;
         // not unrolled: with all BK/4 sub-steps in flight the hoisted fragment loads (4 x 17 f64
         // registers) spill; one sub-step = (TM + TN) LDS reads feeding TM * TN MFMAs
@@ -360,17 +381,27 @@ __global__ __launch_bounds__(WM *WN * 64) void k_gemm_f64q(GemmArgs<double> g) {
                 const int nn = wn * WC + j * BNW + lbn;
                 bf[j] = BLAY == 1 ? bs[nn * PB + kk] : bs[kk * PB + nn];
             }
+            RC_STAMP(1)
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
                 for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f64_4x4x4f64(af[i], bf[j], acc[i][j], 0, 0, 0);
+            RC_STAMP(2)
         }
         if (it + 1 < nk) {
             sa.store(smem + (buf ^ 1) * STAGE, tid);
             sb.store(smem + A_ELEMS + (buf ^ 1) * STAGE, tid);
         }
+        RC_STAMP(3)
         __syncthreads();
+        RC_STAMP(4)
     }
+#ifdef RC_GEMM_TIMING
+    if (blockIdx.x == 0 && blockIdx.y == 0 && tid == 0 && g.M * g.N * g.K > (1ll << 32)) {
+        for (int k2 = 0; k2 < 5; ++k2) g_gemm_dbg[k2] = tacc[k2];
+        g_gemm_dbg[5] = (unsigned long long)nk;
+    }
+#endif
 
     // ---- epilogue: D lane l = 16*i + 4*b + j ---------------------------------------------
     //   ORIENT 0: row = i (l >> 4),           col = 4*b + j (l & 15)
@@ -618,6 +649,9 @@ void gemm(rc_context *c, T alpha, Mat<T> a, Mat<T> b, T beta, Mat<T> cm) {
     }
 }
 
+#ifdef RC_GEMM_TIMING
+extern "C" void rc_debug_gemm_timing(unsigned long long *out) { (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_gemm_dbg), 8 * sizeof(unsigned long long)); }
+#endif
 template void gemm<double>(rc_context *, double, Mat<double>, Mat<double>, double, Mat<double>);
 template void gemm<float>(rc_context *, float, Mat<float>, Mat<float>, float, Mat<float>);
 
