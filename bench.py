@@ -162,8 +162,34 @@ def main():
     s0 = lanes[0]["bufs"]["s"]
     assert orth < 1e-10 and bool((s0[:-1] >= s0[1:]).all()) and float(s0[-1]) > 0, "bench sanity check failed"
 
+    def profile_samples(ln, lib, n):
+        out = []
+        for _ in range(2):  # untimed: lane's buffers back into the TLBs / caches
+            ln["call"]()
+        ln["ctx"].synchronize()
+        lib.rc_profile_enable(ln["ctx"]._h, 1)
+        for _ in range(n):
+            lib.rc_profile_reset(ln["ctx"]._h)
+            ln["call"]()
+            cnt = ctypes.c_int32(0)
+            ln["ctx"].check(lib.rc_profile_count(ln["ctx"]._h, ctypes.byref(cnt)))
+            one = {}
+            for i in range(cnt.value):
+                name = ctypes.create_string_buffer(192)
+                ms = ctypes.c_double(0)
+                calls = ctypes.c_int64(0)
+                lib.rc_profile_get(ln["ctx"]._h, i, name, 192, ctypes.byref(ms), ctypes.byref(calls))
+                one[name.value.decode()] = ms.value / max(calls.value, 1)
+            out.append(one)
+        lib.rc_profile_enable(ln["ctx"]._h, 0)
+        return out
+
     # ---- warm-up, then K timed steps -----------------------------------------------------
     for i in range(args.warmup):
+        step(i)
+    sync_all()
+    prof_before = profile_samples(lanes[0], _lib.lib(), 4)
+    for i in range(min(args.warmup, S)):
         step(i)
     sync_all()
     if dist is not None:
@@ -187,26 +213,18 @@ def main():
         elapsed = float(t.item())
 
     # ---- stage / kernel timers: HIP events on lane 0's own stream, eager launches --------
-    prof = {}
-    ln = lanes[0]
+    # one (reset -> call -> read) cycle per sample, so every launch is seen individually; the samples taken before
+    # the timed region (prof_before, below the warm-up) and after it are both reported and the MEDIAN is used:
+    # right after minutes of sustained f64 MFMA load single eager launches sporadically run several times slower
+    # (power management), which an average would fold into the kernel's figure.
     lib = _lib.lib()
-    for _ in range(4):  # untimed: lane 0's buffers back into the TLBs / caches after S - 1 other lanes ran
-        ln["call"]()
-    ln["ctx"].synchronize()
-    lib.rc_profile_enable(ln["ctx"]._h, 1)
-    lib.rc_profile_reset(ln["ctx"]._h)
-    nprof = 8
-    for _ in range(nprof):
-        ln["call"]()
-    cnt = ctypes.c_int32(0)
-    ln["ctx"].check(lib.rc_profile_count(ln["ctx"]._h, ctypes.byref(cnt)))
-    for i in range(cnt.value):
-        name = ctypes.create_string_buffer(192)
-        ms = ctypes.c_double(0)
-        calls = ctypes.c_int64(0)
-        lib.rc_profile_get(ln["ctx"]._h, i, name, 192, ctypes.byref(ms), ctypes.byref(calls))
-        prof[name.value.decode()] = (ms.value, calls.value)
-    lib.rc_profile_enable(ln["ctx"]._h, 0)
+    ln = lanes[0]
+    samples_after = profile_samples(ln, lib, 8)
+    samples = prof_before + samples_after
+    prof = {}
+    for name in set().union(*[set(x) for x in samples]):
+        vals = sorted(x[name] for x in samples if name in x)
+        prof[name] = (vals[len(vals) // 2], 1)
 
     if args.profile_concurrent and rank == 0:
         for l2 in lanes:
@@ -256,9 +274,11 @@ def main():
                 traffic = None
         roof = {"bound": "mfma", "kernel": "k_gemm_f64q (sketch Y = A*Omega, %dx%dx%d, run as Y^T = Omega^T A^T)" % (m, l, n), "achieved": round(achieved, 3),
                 "peak": F64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / F64_MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
-                "avg_launch_ms": round(ms_launch, 4), "launches_timed": prof[key][1],
+                "avg_launch_ms": round(ms_launch, 4), "launches_timed": len(samples),
+                "launch_ms_samples_before_timed_region": [round(x[key], 4) for x in prof_before if key in x],
+                "launch_ms_samples_after_timed_region": [round(x[key], 4) for x in samples_after if key in x],
                 "flops_per_launch": fl["sketch_gemm"], "hbm_gbs_algorithmic": round(8.0 * m * n / (ms_launch * 1e-3) / 1e9, 1),
-                "method": "HIP events on the launching stream around each launch (rc_profile_*), eager pass after the timed region"}
+                "method": "HIP events on the launching stream around each launch (rc_profile_*): median of the eager single-stream samples taken right before and right after the timed region"}
 
     # ---- CPU baseline: the oracle in the reference's call shape on this box's host cores --
     cpu = None
