@@ -101,16 +101,14 @@ def main():
     # ---- per-stream state: own matrix, own outputs, own context ------------------------
     lanes = []
     seen_streams = set()
-    hip = None
     for s in range(S):
         if s < 32:
             st = torch.cuda.Stream()
         else:
-            # torch hands out 32 distinct streams per device; further lanes get their own HIP streams
-            if hip is None:
-                hip = ctypes.CDLL("libamdhip64.so")
+            # torch hands out 32 distinct streams per device; further lanes get their own HIP streams (through the
+            # library, so that they come from the HIP runtime the library itself is linked against)
             raw = ctypes.c_void_p()
-            assert hip.hipStreamCreateWithFlags(ctypes.byref(raw), ctypes.c_uint(1)) == 0  # hipStreamNonBlocking
+            assert _lib.lib().rc_stream_create(ctypes.c_int32(local_rank), ctypes.byref(raw)) == 0
             st = torch.cuda.ExternalStream(raw.value)
         assert st.cuda_stream not in seen_streams, "duplicate stream handle"
         seen_streams.add(st.cuda_stream)

@@ -32,6 +32,16 @@ extern "C" {
     pub fn rc_create(ctx: *mut *mut rc_context, device: i32, hip_stream: *mut c_void) -> rc_status;
     pub fn rc_destroy(ctx: *mut rc_context) -> rc_status;
     pub fn rc_synchronize(ctx: *mut rc_context) -> rc_status;
+    pub fn rc_set_stream(ctx: *mut rc_context, hip_stream: *mut c_void) -> rc_status;
+    pub fn rc_stream_create(device: i32, hip_stream: *mut *mut c_void) -> rc_status;
+    pub fn rc_stream_destroy(device: i32, hip_stream: *mut c_void) -> rc_status;
+    /// options: 1 tall-skinny fast path, 2 lazy wide QRCP, 3 cooperative wide QRCP, 4 power iteration that really iterates
+    pub fn rc_set_option(ctx: *mut rc_context, option: i32, value: i64) -> rc_status;
+    pub fn rc_get_health(ctx: *mut rc_context, word: *mut i32) -> rc_status;
+    pub fn rc_graph_begin_capture(ctx: *mut rc_context) -> rc_status;
+    pub fn rc_graph_end_capture(ctx: *mut rc_context, graph_exec: *mut *mut c_void) -> rc_status;
+    pub fn rc_graph_launch(ctx: *mut rc_context, graph_exec: *mut c_void) -> rc_status;
+    pub fn rc_graph_destroy(ctx: *mut rc_context, graph_exec: *mut c_void) -> rc_status;
     pub fn rc_last_error_message(ctx: *const rc_context) -> *const c_char;
     pub fn rc_device_malloc(ctx: *mut rc_context, bytes: usize, ptr: *mut *mut c_void) -> rc_status;
     pub fn rc_device_free(ctx: *mut rc_context, ptr: *mut c_void) -> rc_status;

@@ -74,6 +74,10 @@ int32_t rc_abi_version(void);
 rc_status rc_create(rc_context **ctx, int32_t device, void *hip_stream);
 rc_status rc_destroy(rc_context *ctx);
 rc_status rc_set_stream(rc_context *ctx, void *hip_stream);
+/* Stream helpers for hosts without HIP bindings: a non-blocking hipStream_t on `device`, to be passed to
+ * rc_create / rc_set_stream (one context + stream per independent compression in flight). */
+rc_status rc_stream_create(int32_t device, void **hip_stream);
+rc_status rc_stream_destroy(int32_t device, void *hip_stream);
 rc_status rc_synchronize(rc_context *ctx);
 /* Pre-size the internal workspace arena (bytes); optional, it grows on demand. */
 rc_status rc_reserve_workspace(rc_context *ctx, size_t bytes);

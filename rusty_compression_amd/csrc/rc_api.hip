@@ -669,6 +669,21 @@ rc_status rc_create(rc_context **ctx, int32_t device, void *hip_stream) {
     return RC_OK;
 }
 
+rc_status rc_stream_create(int32_t device, void **hip_stream) {
+    if (!hip_stream) return RC_INVALID_ARGUMENT;
+    *hip_stream = nullptr;
+    DeviceGuard dg(device);
+    hipStream_t st = nullptr;
+    if (hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess) return RC_RUNTIME_ERROR;
+    *hip_stream = st;
+    return RC_OK;
+}
+rc_status rc_stream_destroy(int32_t device, void *hip_stream) {
+    if (!hip_stream) return RC_OK;
+    DeviceGuard dg(device);
+    return hipStreamDestroy(static_cast<hipStream_t>(hip_stream)) == hipSuccess ? RC_OK : RC_RUNTIME_ERROR;
+}
+
 rc_status rc_destroy(rc_context *ctx) {
     if (!ctx) return RC_OK;
     {
