@@ -77,6 +77,10 @@ __global__ void k_coop_gate(unsigned *sem, unsigned need, unsigned budget, unsig
 
 }  // namespace
 
+#ifdef RC_COOP_TIMING
+__device__ unsigned long long g_coop_dbg[8];
+#endif
+
 template <typename T>
 struct WqCoopArgs {
     Mat<T> w;          // m x n column-major input (read once, never written)
@@ -147,11 +151,18 @@ __global__ __launch_bounds__(512) void k_wq_coop(WqCoopArgs<T> a) {
     __syncthreads();
     bool aborted = sh_exit != 0;
 
-    // per-phase clocks of workgroup 0 (diagnostic build only: -DRC_COOP_TIMING; costs ~100 VGPRs)
+    // per-phase s_memtime totals of workgroup 0 (diagnostic build only: -DRC_COOP_TIMING, tools/coop_timing.py;
+    // one stamp costs ~470 cycles)
 #ifdef RC_COOP_TIMING
-    long long tph[6] = {0, 0, 0, 0, 0, 0};
-    long long tlast = clock64();
-#define RC_TICK(k) { const long long now = clock64(); tph[k] += now - tlast; tlast = now; }
+    unsigned long long tph[6] = {0, 0, 0, 0, 0, 0}, tlast;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tlast)::"memory");
+#define RC_TICK(k)                                                                        \
+    {                                                                                     \
+        unsigned long long now_;                                                          \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(now_)::"memory");   \
+        tph[k] += now_ - tlast;                                                           \
+        tlast = now_;                                                                     \
+    }
 #else
 #define RC_TICK(k)
 #endif
@@ -378,7 +389,7 @@ __global__ __launch_bounds__(512) void k_wq_coop(WqCoopArgs<T> a) {
 #undef RC_TICK
 #ifdef RC_COOP_TIMING
     if (wg == 0 && tid == 0)
-        printf("k_wq_coop wg0 clocks: A %lld  post %lld  barrier %lld  fetch %lld  select+larfg %lld  C %lld\n", tph[0], tph[1], tph[2], tph[3], tph[4], tph[5]);
+        for (int k2 = 0; k2 < 6; ++k2) g_coop_dbg[k2] = tph[k2];
 #endif
 
     // ---- write the not yet written blocks, the permutation, and release the budget ------------
@@ -468,6 +479,9 @@ void geqp3_wide_coop(rc_context *c, Mat<T> w, Mat<T> wf, int64_t kmax, int64_t *
 #undef RC_COOP
 }
 
+#ifdef RC_COOP_TIMING
+extern "C" void rc_debug_coop_timing(unsigned long long *out) { (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_coop_dbg), 8 * sizeof(unsigned long long)); }
+#endif
 template bool wide_coop_supported<double>(int64_t, int64_t);
 template bool wide_coop_supported<float>(int64_t, int64_t);
 template void geqp3_wide_coop<double>(rc_context *, Mat<double>, Mat<double>, int64_t, int64_t *, double *, int *);
