@@ -247,6 +247,43 @@ def test_svd_cores_beyond_the_lds_limit(dtype, shape):
         assert np.abs(vt[:lead] @ vt[:lead].T - np.eye(lead)).max() <= (1e-11 if f64 else 1e-4)
 
 
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_degenerate_shapes_and_zero_matrices(dtype):
+    """1 x 1, single rows / columns, all-zero inputs (every reflector is the identity: tau = 0) and rank-1 inputs
+    through pivoted QR / LQ, SVD and the IDs, against the oracle."""
+    f64 = dtype == np.float64
+    tol = 1e-13 if f64 else 1e-5
+    rng = np.random.default_rng(3)
+    for shape in [(1, 1), (1, 5), (5, 1), (2, 2), (3, 7), (7, 3)]:
+        a = rng.standard_normal(shape).astype(dtype)
+        q, r, ind = (npy(t) for t in rc.pivoted_qr(a))
+        oq, orr, oind = o.pivoted_qr(a)
+        assert np.array_equal(ind, oind), shape
+        assert rel(q, oq) <= 10 * tol and rel(r, orr) <= 10 * tol, shape
+        l, ql, indl = (npy(t) for t in rc.pivoted_lq(a))
+        assert rel(l @ ql, a[indl, :]) <= 10 * tol, shape
+        u, s, vt = (npy(t) for t in rc.compute_svd(a))
+        assert np.abs(s - o.compute_svd(a)[1]).max() <= 10 * tol * max(1.0, float(np.abs(a).max())), shape
+        assert rel((u * s) @ vt, a) <= 10 * tol, shape
+        qr = rc.QR.compute_from(a)
+        assert rc.rel_diff_fro(qr.column_id().to_mat(), a) <= 100 * tol
+        assert rc.rel_diff_fro(rc.LQ.compute_from(a).row_id().to_mat(), a) <= 100 * tol
+    # all-zero matrix: LAPACK leaves the identity permutation, Q = [I; 0], R = 0
+    z = np.zeros((6, 4), dtype=dtype)
+    q, r, ind = (npy(t) for t in rc.pivoted_qr(z))
+    oq, orr, oind = o.pivoted_qr(z)
+    assert np.array_equal(ind, oind) and np.array_equal(r, orr) and np.array_equal(q, oq)
+    u, s, vt = (npy(t) for t in rc.compute_svd(z))
+    assert np.all(s == 0) and np.all(np.isfinite(u)) and np.all(np.isfinite(vt))
+    # rank one: one non-zero singular value, the pivot is the column of largest norm
+    x = np.outer(rng.standard_normal(40), rng.standard_normal(30)).astype(dtype)
+    q, r, ind = (npy(t) for t in rc.pivoted_qr(x))
+    assert ind[0] == int(np.argmax(np.linalg.norm(x, axis=0)))
+    assert rel(q @ r, x[:, ind]) <= 100 * tol
+    s = npy(rc.compute_svd(x)[1])
+    assert abs(s[0] - np.linalg.norm(x)) <= 100 * tol * np.linalg.norm(x) and s[1] <= 1e3 * tol * s[0]
+
+
 # ---------------------------------------------------------------- compress / to_mat / IDs (a7-a10, a13-a16)
 @pytest.mark.parametrize("dtype,shape", [(np.float64, (100, 50)), (np.float32, (100, 50)), (np.float64, (50, 100)), (np.float32, (50, 100))])
 def test_qr_compression_and_ids_reference_properties(dtype, shape):
