@@ -27,9 +27,10 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-# one hardware queue per in-flight compression (the HIP default of 4 serialises more streams);
-# must be set before the HIP runtime initialises
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "32")
+# hardware queues for the in-flight compressions (the HIP default of 4 serialises the streams); must be set before
+# the HIP runtime initialises.  Measured (tools/stream_sweep.sh): 24 queues x 40 streams is the best point (917-922
+# compressions/s), 8 queues 600, 16 queues 800, 32 queues 845-910, 48 queues with >= 48 streams collapses to 316.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "24")
 
 F64_MFMA_PEAK_TFLOPS = 78.6   # MI355X f64 matrix peak (vendor datasheet value)
 HBM_PEAK_GBS = 8000.0         # /opt/skills/guides/MI355X_MICROARCH.md: 8 TB/s spec (6.3 TB/s achievable)
@@ -60,7 +61,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=256)
     ap.add_argument("--warmup", type=int, default=32)
-    ap.add_argument("--streams", type=int, default=48, help="independent compressions in flight per GPU")
+    ap.add_argument("--streams", type=int, default=40, help="independent compressions in flight per GPU")
     ap.add_argument("--size", type=int, default=8192)
     ap.add_argument("--rank", type=int, default=128)
     ap.add_argument("--oversample", type=int, default=5)
