@@ -177,21 +177,25 @@ __global__ __launch_bounds__(LPP == 16 ? 1024 : 512) void k_jacobi_lds(Mat<T> g,
 // ---------------------------------------------------------------------------
 // V = J_1 J_2 ... applied to I, row by row: one wave per row of V.
 // ---------------------------------------------------------------------------
-template <typename T>
+template <typename T, int RPW>
 __global__ __launch_bounds__(256) void k_jacobi_replay_v(int n, const Rot<T> *log, const int *sweeps, const int *order, Mat<T> vc) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     T *rows = reinterpret_cast<T *>(smem_raw);
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const int row = blockIdx.x * 4 + wv;
-    if (row >= n) return;  // whole wave; no barriers in this kernel
-    T *v = rows + (size_t)wv * (n + 1);
     const int N = (n + 1) & ~1, npairs = N / 2;
-    for (int j = lane; j < n; j += 64) v[j] = (j == row) ? (T)1 : (T)0;
     const int ns = *sweeps;
     if (npairs <= 64) {
-        // one pair per lane: the log is one 64-entry line per round, fetched PF rounds ahead so that the
-        // dependent chain of rounds does not pay an L2 latency each
+        // One pair per lane.  A wave carries RPW independent rows through the rounds: the chain of a row is a
+        // dependent LDS read -> FMA -> LDS write per round, so the rows' chains interleave and a quarter of the
+        // waves (and CUs) does the same work in the same time.  The log is one 64-entry line per round, fetched
+        // PF rounds ahead so that the chain does not pay an L2 latency per round.
         constexpr int PF = 8;
+        const int row0 = (blockIdx.x * 4 + wv) * RPW;
+        if (row0 >= n) return;  // whole wave; no barriers in this kernel
+        T *v = rows + (size_t)wv * RPW * (n + 1);
+#pragma unroll
+        for (int rr = 0; rr < RPW; ++rr)
+            for (int j = lane; j < n; j += 64) v[rr * (n + 1) + j] = (j == row0 + rr) ? (T)1 : (T)0;
         const int total = ns * (N - 1);
         const bool has = lane < npairs;
         // circle-method pair of this lane, advanced round by round (no integer modulo in the chain):
@@ -213,17 +217,29 @@ __global__ __launch_bounds__(256) void k_jacobi_replay_v(int n, const Rot<T> *lo
                     pr = pr + 1 == N - 1 ? 0 : pr + 1;
                     qr = qr + 1 == N - 1 ? 0 : qr + 1;
                     if (rt[u].s != (T)0) {
-                        const T a = v[p], b = v[q];
-                        v[p] = rt[u].c * a - rt[u].s * b;
-                        v[q] = rt[u].s * a + rt[u].c * b;
+                        T a[RPW], b[RPW];
+#pragma unroll
+                        for (int rr = 0; rr < RPW; ++rr) { a[rr] = v[rr * (n + 1) + p]; b[rr] = v[rr * (n + 1) + q]; }
+#pragma unroll
+                        for (int rr = 0; rr < RPW; ++rr) {
+                            v[rr * (n + 1) + p] = rt[u].c * a[rr] - rt[u].s * b[rr];
+                            v[rr * (n + 1) + q] = rt[u].s * a[rr] + rt[u].c * b[rr];
+                        }
                     }
                     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
                 }
             }
         }
-        for (int j = lane; j < n; j += 64) vc.at(row, order[j]) = v[j];
+#pragma unroll
+        for (int rr = 0; rr < RPW; ++rr)
+            if (row0 + rr < n)
+                for (int j = lane; j < n; j += 64) vc.at(row0 + rr, order[j]) = v[rr * (n + 1) + j];
         return;
     }
+    const int row = blockIdx.x * 4 + wv;
+    if (row >= n) return;  // whole wave; no barriers in this kernel
+    T *v = rows + (size_t)wv * (n + 1);
+    for (int j = lane; j < n; j += 64) v[j] = (j == row) ? (T)1 : (T)0;
     for (int sw = 0; sw < ns; ++sw)
         for (int r = 0; r < N - 1; ++r) {
             const Rot<T> *lr = log + ((size_t)sw * (N - 1) + r) * npairs;
@@ -378,8 +394,13 @@ static void launch_lds(rc_context *c, Mat<T> g, Mat<T> uc, T *s, Mat<T> vc, size
     // one LPP-lane group per pair, rounded up to whole waves
     const int threads = std::min(LPP == 16 ? 1024 : 512, std::max(64, (((N / 2) * LPP + 63) / 64) * 64));
     hipLaunchKernelGGL(kern, dim3(1), dim3(threads), lds, c->stream, g, log, sweeps, uc, s, order, max_sweeps);
-    const size_t lds_v = 4 * (size_t)(n + 1) * sizeof(T);
-    hipLaunchKernelGGL(k_jacobi_replay_v<T>, dim3((unsigned)((n + 3) / 4)), dim3(256), lds_v, c->stream, n, log, sweeps, order, vc);
+    static const int rpw_env = [] { const char *e = getenv("RC_REPLAY_RPW"); return e ? atoi(e) : 1; }();
+    const int rpw = (N / 2 <= 64) ? (rpw_env == 2 || rpw_env == 4 ? rpw_env : 1) : 1;  // rows per wave: 1 measured best (913 vs 903 compressions/s at 4)
+    const size_t lds_v = 4 * (size_t)rpw * (n + 1) * sizeof(T);
+    const dim3 grid((unsigned)((n + 4 * rpw - 1) / (4 * rpw)));
+    if (rpw == 4) hipLaunchKernelGGL((k_jacobi_replay_v<T, 4>), grid, dim3(256), lds_v, c->stream, n, log, sweeps, order, vc);
+    else if (rpw == 2) hipLaunchKernelGGL((k_jacobi_replay_v<T, 2>), grid, dim3(256), lds_v, c->stream, n, log, sweeps, order, vc);
+    else hipLaunchKernelGGL((k_jacobi_replay_v<T, 1>), grid, dim3(256), lds_v, c->stream, n, log, sweeps, order, vc);
     if (c->prof_on && !c->capturing) {  // diagnostic: number of sweeps, reported through the profile table
         int h = 0;
         (void)hipStreamSynchronize(c->stream);
