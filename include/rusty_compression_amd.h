@@ -122,7 +122,11 @@ rc_status rc_graph_destroy(rc_context *ctx, void *graph_exec);
 /* RC_OPT_POWER_ITERATION_FIXED (default 0): rc_sample_range_power_iteration_* performs it_count power steps
  * (Y <- A orth(A^H orth(Y))) as the reference documents; 0 reproduces the reference's behaviour, where a shadowed
  * loop variable leaves exactly one step (src/random_sampling.rs:145-153). */
-enum { RC_OPT_TALL_SKINNY_FAST_PATH = 1, RC_OPT_WIDE_LAZY_QRCP = 2, RC_OPT_WIDE_COOP_QRCP = 3, RC_OPT_POWER_ITERATION_FIXED = 4 };
+/* RC_OPT_FORK_BRANCHES (default 0): 1 makes rc_rsvd_id_* run its two independent consumers of B = Q^H A (the SVD and
+ * the pivoted-QR / ID branch) side by side on a second stream owned by the context (fork / join with events; captured
+ * into the same hipGraph).  Latency of one compression 6.8 -> 5.6 ms; with dozens of such graphs in flight the
+ * throughput measured lower (680 vs 913 compressions/s), hence opt-in. */
+enum { RC_OPT_TALL_SKINNY_FAST_PATH = 1, RC_OPT_WIDE_LAZY_QRCP = 2, RC_OPT_WIDE_COOP_QRCP = 3, RC_OPT_POWER_ITERATION_FIXED = 4, RC_OPT_FORK_BRANCHES = 5 };
 rc_status rc_set_option(rc_context *ctx, int32_t option, int64_t value);
 rc_status rc_get_health(rc_context *ctx, int32_t *word);
 

@@ -24,18 +24,36 @@ void rc_context::retire_arena() {
     arena_size = 0;
 }
 
-void rc_context::reset_arena() {
-    if (!overflow.empty()) {
+void rc_context::swap_arena() {
+    std::swap(arena, aux_arena.base);
+    std::swap(arena_size, aux_arena.size);
+    std::swap(arena_off, aux_arena.off);
+    std::swap(arena_high, aux_arena.high);
+    std::swap(overflow, aux_arena.overflow);
+}
+
+// the active arena (the fields of the context), whose users were issued on `st`
+static void reset_active_arena(rc_context *c, hipStream_t st) {
+    if (!c->overflow.empty()) {
         // the previous call outgrew the arena: rebuild it once, big enough
-        (void)hipStreamSynchronize(stream);
-        for (void *p : overflow) (void)hipFree(p);
-        overflow.clear();
-        size_t want = arena_high + arena_high / 4 + (1u << 20);
-        retire_arena();
-        if (hipMalloc(reinterpret_cast<void **>(&arena), want) == hipSuccess) arena_size = want;
+        (void)hipStreamSynchronize(st);
+        for (void *p : c->overflow) (void)hipFree(p);
+        c->overflow.clear();
+        size_t want = c->arena_high + c->arena_high / 4 + (1u << 20);
+        c->retire_arena();
+        if (hipMalloc(reinterpret_cast<void **>(&c->arena), want) == hipSuccess) c->arena_size = want;
     }
-    arena_off = 0;
-    arena_high = 0;
+    c->arena_off = 0;
+    c->arena_high = 0;
+}
+
+void rc_context::reset_arena() {
+    if (aux_stream) {  // the side arena obeys the same rules (its work was joined into `stream` by the call that used it)
+        swap_arena();
+        reset_active_arena(this, aux_stream);
+        swap_arena();
+    }
+    reset_active_arena(this, stream);
 }
 
 void *rc_context::alloc_bytes(size_t bytes) {
@@ -108,6 +126,16 @@ void rc_context::release_all() {
     if (arena) (void)hipFree(arena);
     arena = nullptr;
     arena_size = 0;
+    if (aux_stream) (void)hipStreamSynchronize(aux_stream);
+    for (void *p : aux_arena.overflow) (void)hipFree(p);
+    aux_arena.overflow.clear();
+    if (aux_arena.base) (void)hipFree(aux_arena.base);
+    aux_arena = ArenaState();
+    if (fork_ev) (void)hipEventDestroy(fork_ev);
+    if (join_ev) (void)hipEventDestroy(join_ev);
+    if (aux_stream) (void)hipStreamDestroy(aux_stream);
+    fork_ev = join_ev = nullptr;
+    aux_stream = nullptr;
     if (pinned) (void)hipHostFree(pinned);
     pinned = nullptr;
 }
@@ -536,6 +564,44 @@ void sample_range_adaptive(rc_context *c, Mat<T> a, double rel_tol_d, int64_t s,
     RC_HIP(hipStreamSynchronize(c->stream));
 }
 
+// Fork / join of a side branch onto the context's second stream (created on first use, outside graph capture).
+// While the side branch is issued, `stream` and the arena of the context are the side ones, so every helper
+// below works unchanged; back() returns to the main stream, join() makes the main stream wait for the side one.
+struct Fork {
+    rc_context *c;
+    hipStream_t main_stream = nullptr;
+    bool active = false;
+    explicit Fork(rc_context *ctx, bool want) : c(ctx) {
+        if (!want || !c->opt_fork) return;
+        if (!c->aux_stream) {
+            if (c->capturing) return;  // cannot create a stream inside a capture: this graph stays single-stream
+            RC_HIP(hipStreamCreateWithFlags(&c->aux_stream, hipStreamNonBlocking));
+            RC_HIP(hipEventCreateWithFlags(&c->fork_ev, hipEventDisableTiming));
+            RC_HIP(hipEventCreateWithFlags(&c->join_ev, hipEventDisableTiming));
+        }
+        main_stream = c->stream;
+        RC_HIP(hipEventRecord(c->fork_ev, main_stream));
+        RC_HIP(hipStreamWaitEvent(c->aux_stream, c->fork_ev, 0));
+        c->stream = c->aux_stream;
+        c->swap_arena();
+        active = true;
+    }
+    void back() {
+        if (!active) return;
+        RC_HIP(hipEventRecord(c->join_ev, c->aux_stream));
+        c->stream = main_stream;
+        c->swap_arena();
+    }
+    void join() {
+        if (!active) return;
+        RC_HIP(hipStreamWaitEvent(main_stream, c->join_ev, 0));
+        active = false;
+    }
+    ~Fork() {  // error path: leave the context on its main stream / arena
+        if (active && c->stream == c->aux_stream) { c->stream = main_stream; c->swap_arena(); }
+    }
+};
+
 // cfg3 "rSVD + ID" without host synchronisation
 template <typename T>
 void rsvd_id(rc_context *c, Mat<T> a, int64_t k, int64_t p, Mat<T> omega, uint64_t seed, const rc_rsvd_id_out &o) {
@@ -561,13 +627,10 @@ void rsvd_id(rc_context *c, Mat<T> a, int64_t k, int64_t p, Mat<T> omega, uint64
         wq = tmp_colmajor<T>(c, k, n);
         copy_mat(c, b, wq);
     }
-    if (o.u.data || o.s || o.vt.data) {
-        RC_REQUIRE(o.u.data && o.s && o.vt.data, RC_INVALID_ARGUMENT, "rsvd_id: u, s, vt must be given together");
-        ProfScope ps(c, "stage:svd of B + U=Q Ub");
-        Mat<T> ub = tmp_colmajor<T>(c, k, k);
-        svd_core(c, b.t(), true, ub, static_cast<T *>(o.s), from_c<T>(o.vt));  // destroys b
-        gemm<T>(c, 1, range, ub, 0, from_c<T>(o.u));
-    }
+    const bool want_svd = o.u.data || o.s || o.vt.data;
+    if (want_svd) RC_REQUIRE(o.u.data && o.s && o.vt.data, RC_INVALID_ARGUMENT, "rsvd_id: u, s, vt must be given together");
+    // the two consumers of B are independent: the ID branch goes to the side stream, the SVD branch stays here
+    Fork fork(c, want_svd && want_id);
     if (want_id) {
         ProfScope ps(c, "stage:qrcp of B + column_id");
         Mat<T> qb = tmp_colmajor<T>(c, k, k);
@@ -581,6 +644,14 @@ void rsvd_id(rc_context *c, Mat<T> a, int64_t k, int64_t p, Mat<T> omega, uint64
             qr_column_id(c, q, r, ind, from_c<T>(o.id_c), from_c<T>(o.id_z));
         }
     }
+    fork.back();
+    if (want_svd) {
+        ProfScope ps(c, "stage:svd of B + U=Q Ub");
+        Mat<T> ub = tmp_colmajor<T>(c, k, k);
+        svd_core(c, b.t(), true, ub, static_cast<T *>(o.s), from_c<T>(o.vt));  // destroys b
+        gemm<T>(c, 1, range, ub, 0, from_c<T>(o.u));
+    }
+    fork.join();
 }
 
 // cfg5 unit: rank-k column ID of a dense matrix through the truncated factorization
@@ -756,7 +827,7 @@ rc_status rc_graph_begin_capture(rc_context *ctx) {
     if (!ctx) return RC_INVALID_ARGUMENT;
     DeviceGuard dg(ctx->device);
     if (ctx->capturing) { ctx->last_error = "capture already in progress"; return RC_INVALID_ARGUMENT; }
-    if (!ctx->overflow.empty()) ctx->reset_arena();  // settle the arena before anything is baked into a graph
+    if (!ctx->overflow.empty() || !ctx->aux_arena.overflow.empty()) ctx->reset_arena();  // settle the arenas before anything is baked into a graph
     hipError_t e = hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal);
     if (e != hipSuccess) { ctx->last_error = hipGetErrorString(e); return RC_RUNTIME_ERROR; }
     ctx->capturing = true;
@@ -806,6 +877,7 @@ rc_status rc_set_option(rc_context *ctx, int32_t option, int64_t value) {
         case RC_OPT_WIDE_LAZY_QRCP: ctx->opt_wide_lazy = value != 0; return RC_OK;
         case RC_OPT_WIDE_COOP_QRCP: ctx->opt_wide_coop = value != 0; return RC_OK;
         case RC_OPT_POWER_ITERATION_FIXED: ctx->opt_power_fixed = value != 0; return RC_OK;
+        case RC_OPT_FORK_BRANCHES: ctx->opt_fork = value != 0; return RC_OK;
         default: ctx->last_error = "unknown option"; return RC_INVALID_ARGUMENT;
     }
 }

@@ -99,6 +99,14 @@ struct rc_context {
     int live_graphs = 0;
     std::vector<void *> retired;
     void retire_arena();
+    // Second stream + second arena: the two consumers of the projection B (SVD branch, pivoted-QR / ID branch of
+    // rc_rsvd_id) are independent and run side by side (fork / join with events; capturable in a hipGraph).  While
+    // the side branch is being issued `stream` and the arena fields above are swapped with these.
+    hipStream_t aux_stream = nullptr;
+    hipEvent_t fork_ev = nullptr, join_ev = nullptr;
+    struct ArenaState { char *base = nullptr; size_t size = 0, off = 0, high = 0; std::vector<void *> overflow; } aux_arena;
+    void swap_arena();
+    int opt_fork = 0;  // 1: rc_rsvd_id runs its two branches side by side (lower latency; measured LOWER throughput with many graphs in flight)
     void *pinned = nullptr;             // small pinned host buffer for scalar read-backs
     size_t pinned_size = 0;
 

@@ -399,6 +399,61 @@ def test_sketch_rsvd_and_range_qr_match_golden():
     assert rel(npy(cid.c), g["id_c"]) <= 1e-10 and rel(npy(cid.z), g["id_z"]) <= 1e-9
 
 
+def test_fused_pipeline_with_forked_branches_is_bit_identical():
+    """RC_OPT_FORK_BRANCHES: the SVD and the ID branch of rc_rsvd_id on two streams (fork / join), eager and replayed
+    from a hipGraph, give exactly the results of the single-stream order."""
+    import ctypes
+
+    from rusty_compression_amd import _lib
+
+    lib = _lib.lib()
+    st = torch.cuda.Stream()
+    with torch.cuda.stream(st):
+        ctx = _lib.Context(torch.cuda.current_device(), st.cuda_stream)
+        g = torch.Generator(device="cpu").manual_seed(9)
+        m, n, k, p = 1536, 1280, 48, 5
+        a = torch.randn(m, n, dtype=torch.float64, generator=g).cuda()
+        om = torch.randn(n, k + p, dtype=torch.float64, generator=g).cuda()
+        mk = lambda r, c: torch.zeros((r, c), dtype=torch.float64, device="cuda")  # noqa: E731
+
+        def outputs():
+            b = dict(range_q=mk(m, k), u=mk(m, k), s=torch.zeros(k, dtype=torch.float64, device="cuda"), vt=mk(k, n), qr_q=mk(m, k), qr_r=mk(k, n),
+                     qr_ind=torch.zeros(n, dtype=torch.int64, device="cuda"), id_c=mk(m, k), id_z=mk(k, n))
+            o_ = _lib.rc_rsvd_id_out(_lib.mat(b["range_q"]), _lib.mat(b["u"]), ctypes.c_void_p(b["s"].data_ptr()), _lib.mat(b["vt"]), _lib.mat(b["qr_q"]),
+                                     _lib.mat(b["qr_r"]), ctypes.c_void_p(b["qr_ind"].data_ptr()), _lib.mat(b["id_c"]), _lib.mat(b["id_z"]))
+            return b, o_
+
+        def run(o_):
+            ctx.call("rc_rsvd_id_f64", _lib.mat(a), ctypes.c_int64(k), ctypes.c_int64(p), _lib.mat(om), ctypes.c_uint64(0), ctypes.byref(o_))
+
+        ref, oref = outputs()
+        run(oref)
+        ctx.synchronize()
+        ctx.set_option(_lib.RC_OPT_FORK_BRANCHES, 1)
+        got, ogot = outputs()
+        run(ogot)
+        ctx.synchronize()
+        for key in ref:
+            assert torch.equal(ref[key], got[key]), key
+        graph = ctypes.c_void_p(None)
+        rep, orep = outputs()
+        run(orep)  # sizes the side arena for this output set
+        ctx.synchronize()
+        ctx.check(lib.rc_graph_begin_capture(ctx._h))
+        run(orep)
+        ctx.check(lib.rc_graph_end_capture(ctx._h, ctypes.byref(graph)))
+        for t in rep.values():
+            t.zero_()
+        for _ in range(3):
+            ctx.check(lib.rc_graph_launch(ctx._h, graph))
+        ctx.synchronize()
+        for key in ref:
+            assert torch.equal(ref[key], rep[key]), key
+        assert ctx.get_health() == 0
+        ctx.check(lib.rc_graph_destroy(ctx._h, graph))
+        ctx.close()
+
+
 def test_power_iteration_fixed_mode_is_opt_in_and_matches_the_documented_algorithm():
     """RC_OPT_POWER_ITERATION_FIXED: it_count real power steps; the default keeps
     the reference's shadowing quirk (one step).  Oracle: oracle/ref_lapack.sample_range_power_iteration(fixed=True)."""
