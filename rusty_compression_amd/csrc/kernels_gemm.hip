@@ -294,7 +294,11 @@ __device__ unsigned long long g_gemm_dbg[8];
 #define RC_STAMP(k)
 #endif
 
-template <int ALAY, int BLAY, int BM, int BN, int BK, int WM, int WN, int VEC, int ORIENT>
+// GLDS: the B operand tile goes global -> LDS directly (global_load_lds_dwordx4: no staging registers, no LDS write
+// pass); needs B stored [K][N] with unit N stride (BLAY == 0: every k-row of the tile is BN contiguous doubles, copied
+// as BN / 128 pieces of 1 KiB into the padded LDS row), full tiles, 16-byte aligned rows (checked by the host).
+// GLDS == 2: the A tile as well (A stored [K][M] with unit M stride, ALAY == 1, M == BM: one 1 KiB piece per k-row).
+template <int ALAY, int BLAY, int BM, int BN, int BK, int WM, int WN, int VEC, int ORIENT, int GLDS = 0>
 __global__ __launch_bounds__(WM *WN * 64) void k_gemm_f64q(GemmArgs<double> g) {
     typedef double T;
     constexpr int NT = WM * WN * 64;
@@ -339,15 +343,42 @@ __global__ __launch_bounds__(WM *WN * 64) void k_gemm_f64q(GemmArgs<double> g) {
 
     StA sa;
     StB sb;
-    sa.init(g.a, m0, kbeg, g.sam, g.sak, tid);
-    sb.init(g.b, n0, kbeg, g.sbn, g.sbk, tid);
+    if (GLDS < 2) sa.init(g.a, m0, kbeg, g.sam, g.sak, tid);
+    if (!GLDS) sb.init(g.b, n0, kbeg, g.sbn, g.sbk, tid);
+    static_assert(!GLDS || (BLAY == 0 && BN % 128 == 0 && (BK * (BN / 128)) % (NT / 64) == 0), "direct-to-LDS B tile: shape");
+    static_assert(GLDS < 2 || (ALAY == 1 && BM == 128 && BK % (NT / 64) == 0), "direct-to-LDS A tile: shape");
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    auto glds_b = [&](int64_t k0, T *bdst) {
+        constexpr int PIECES_ROW = BN >= 128 ? BN / 128 : 1, PER_WAVE = BK * PIECES_ROW / (NT / 64) > 0 ? BK * PIECES_ROW / (NT / 64) : 1;
+#pragma unroll
+        for (int i = 0; i < PER_WAVE; ++i) {
+            const int piece = wave_u * PER_WAVE + i;
+            const int kk = piece / PIECES_ROW, h = piece % PIECES_ROW;
+            const T *src = g.b + (k0 + kk) * g.sbk + (n0 + h * 128 + 2 * lane);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
+                                             (__attribute__((address_space(3))) void *)(bdst + kk * PB + h * 128), 16, 0, 0);
+        }
+    };
+
+    auto glds_a = [&](int64_t k0, T *adst) {
+        constexpr int PER_WAVE = BK / (NT / 64) > 0 ? BK / (NT / 64) : 1;
+#pragma unroll
+        for (int i = 0; i < PER_WAVE; ++i) {
+            const int kk = wave_u * PER_WAVE + i;
+            const T *src = g.a + (k0 + kk) * g.sak + (m0 + 2 * lane);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
+                                             (__attribute__((address_space(3))) void *)(adst + kk * PA), 16, 0, 0);
+        }
+    };
 
     const int64_t nk = kend > kbeg ? cdiv(kend - kbeg, BK) : 0;
     if (nk > 0) {
-        sa.load(m0, g.M, kbeg, kend, 0, g.sam, g.sak, tid);
-        sb.load(n0, g.N, kbeg, kend, 0, g.sbn, g.sbk, tid);
-        sa.store(smem, tid);
-        sb.store(smem + A_ELEMS, tid);
+        if (GLDS == 2) glds_a(kbeg, smem);
+        else sa.load(m0, g.M, kbeg, kend, 0, g.sam, g.sak, tid);
+        if (GLDS) glds_b(kbeg, smem + A_ELEMS);
+        else sb.load(n0, g.N, kbeg, kend, 0, g.sbn, g.sbk, tid);
+        if (GLDS < 2) sa.store(smem, tid);
+        if (!GLDS) sb.store(smem + A_ELEMS, tid);
     }
     __syncthreads();
     constexpr int AM = ORIENT == 0 ? 4 : 16, BNW = ORIENT == 0 ? 16 : 4;
@@ -359,17 +390,14 @@ __global__ __launch_bounds__(WM *WN * 64) void k_gemm_f64q(GemmArgs<double> g) {
         const int buf = (int)(it & 1);
         if (it + 1 < nk) {
             const int64_t koff = (it + 1) * BK;
-            sa.load(m0, g.M, kbeg + koff, kend, koff * g.sak, g.sam, g.sak, tid);
-            sb.load(n0, g.N, kbeg + koff, kend, koff * g.sbk, g.sbn, g.sbk, tid);
+            if (GLDS == 2) glds_a(kbeg + koff, smem + (buf ^ 1) * STAGE);
+            else sa.load(m0, g.M, kbeg + koff, kend, koff * g.sak, g.sam, g.sak, tid);
+            if (GLDS) glds_b(kbeg + koff, smem + A_ELEMS + (buf ^ 1) * STAGE);  // that buffer was last read in tile it - 1
+            else sb.load(n0, g.N, kbeg + koff, kend, koff * g.sbk, g.sbn, g.sbk, tid);
         }
         RC_STAMP(0)
         const T *as = smem + buf * STAGE, *bs = smem + A_ELEMS + buf * STAGE;
-        // not unrolled: with all BK/4 sub-steps in flight the hoisted fragment loads (4 x 17 f64
-        // registers) spill; one sub-step = (TM + TN) LDS reads feeding TM * TN MFMAs
-        // (4-wave instances -- one wave per SIMD with 512 registers, loop fully unrolled -- measured 10-20 % slower)
-#pragma unroll 1
-        for (int ks = 0; ks < BK / 4; ++ks) {
-            T af[TM], bf[TN];
+        auto load_frags = [&](int ks, T *af, T *bf) {
             const int kk = ks * 4 + lk;
 #pragma unroll
             for (int i = 0; i < TM; ++i) {
@@ -381,6 +409,16 @@ __global__ __launch_bounds__(WM *WN * 64) void k_gemm_f64q(GemmArgs<double> g) {
                 const int nn = wn * WC + j * BNW + lbn;
                 bf[j] = BLAY == 1 ? bs[nn * PB + kk] : bs[kk * PB + nn];
             }
+        };
+        {
+        // (two fragment sets with the next sub-step's reads in flight behind the MFMAs -- possible in the direct-to-LDS
+        // instance, which has ~60 registers to spare -- measured 4 % SLOWER than the plain loop)
+        // not unrolled: with all BK/4 sub-steps in flight the hoisted fragment loads (4 x 17 f64
+        // registers) spill; one sub-step = (TM + TN) LDS reads feeding TM * TN MFMAs
+#pragma unroll 1
+        for (int ks = 0; ks < BK / 4; ++ks) {
+            T af[TM], bf[TN];
+            load_frags(ks, af, bf);
             RC_STAMP(1)
 #pragma unroll
             for (int i = 0; i < TM; ++i)
@@ -388,9 +426,10 @@ __global__ __launch_bounds__(WM *WN * 64) void k_gemm_f64q(GemmArgs<double> g) {
                 for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f64_4x4x4f64(af[i], bf[j], acc[i][j], 0, 0, 0);
             RC_STAMP(2)
         }
+        }
         if (it + 1 < nk) {
-            sa.store(smem + (buf ^ 1) * STAGE, tid);
-            sb.store(smem + A_ELEMS + (buf ^ 1) * STAGE, tid);
+            if (GLDS < 2) sa.store(smem + (buf ^ 1) * STAGE, tid);
+            if (!GLDS) sb.store(smem + A_ELEMS + (buf ^ 1) * STAGE, tid);
         }
         RC_STAMP(3)
         __syncthreads();
@@ -491,7 +530,7 @@ static void launch_cfg(rc_context *c, GemmArgs<T> g) {
     }
 }
 
-template <int ALAY, int BLAY, int BM, int BN, int BK, int WM, int WN, int VEC, int ORIENT>
+template <int ALAY, int BLAY, int BM, int BN, int BK, int WM, int WN, int VEC, int ORIENT, int GLDS = 0>
 static void launch_f64q(rc_context *c, GemmArgs<double> g) {
     typedef double T;
     constexpr int NT = WM * WN * 64;
@@ -516,7 +555,7 @@ static void launch_f64q(rc_context *c, GemmArgs<double> g) {
     g.splits = splits;
     ArenaMark mark(c);
     if (splits > 1) g.partial = c->alloc<T>((size_t)splits * g.M * g.N);
-    auto kern = k_gemm_f64q<ALAY, BLAY, BM, BN, BK, WM, WN, VEC, ORIENT>;
+    auto kern = k_gemm_f64q<ALAY, BLAY, BM, BN, BK, WM, WN, VEC, ORIENT, GLDS>;
     static bool attr_set[64] = {};
     if (lds > 48 * 1024 && !attr_set[c->device & 63]) {
         RC_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -551,7 +590,19 @@ static bool launch_shape_f64q(rc_context *c, const GemmArgs<double> &g) {
         else launch_f64q<ALAY, BLAY, 256, 144, 16, 8, 1, VEC, 0>(c, g);
     }
     else if (g.M <= 80) launch_f64q<ALAY, BLAY, 80, 256, 16, 1, 8, VEC, 1>(c, g);
-    else if (g.M <= 128 && vm == 3) launch_f64q<ALAY, BLAY, 128, 256, 16, 1, 8, VEC, 1>(c, g);
+    else if (g.M <= 128 && vm == 3) {
+        static const int glds = env_int("RC_GEMM_GLDS", 2);  // 0: register staging, 1: B tile direct to LDS, 2: A tile too
+        const bool direct = glds && BLAY == 0 && VEC == 2 && g.N % 256 == 0 && g.K % 16 == 0 && g.sbn == 1 && g.sbk % 2 == 0 &&
+                            reinterpret_cast<uintptr_t>(g.b) % 16 == 0;
+        if constexpr (BLAY == 0 && VEC == 2) {
+            if constexpr (ALAY == 1) {
+                const bool direct_a = glds >= 2 && g.M == 128 && g.sam == 1 && g.sak % 2 == 0 && reinterpret_cast<uintptr_t>(g.a) % 16 == 0;
+                if (direct && direct_a) { launch_f64q<ALAY, BLAY, 128, 256, 16, 1, 8, VEC, 1, 2>(c, g); return true; }
+            }
+            if (direct) { launch_f64q<ALAY, BLAY, 128, 256, 16, 1, 8, VEC, 1, 1>(c, g); return true; }
+        }
+        launch_f64q<ALAY, BLAY, 128, 256, 16, 1, 8, VEC, 1>(c, g);
+    }
     else if (g.M <= 136 && vm == 3) launch_f64q<ALAY, BLAY, 136, 256, 16, 2, 4, VEC, 0>(c, g);  // 68 x 64 wave tiles: 17 + 4 fragment reads per 68 MFMAs
     else if (g.M <= 144) {
         if (vm == 1) launch_f64q<ALAY, BLAY, 144, 128, 16, 1, 8, VEC, 1>(c, g);
