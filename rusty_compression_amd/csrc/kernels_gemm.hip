@@ -297,7 +297,12 @@ __device__ unsigned long long g_gemm_dbg[8];
 // GLDS: the B operand tile goes global -> LDS directly (global_load_lds_dwordx4: no staging registers, no LDS write
 // pass); needs B stored [K][N] with unit N stride (BLAY == 0: every k-row of the tile is BN contiguous doubles, copied
 // as BN / 128 pieces of 1 KiB into the padded LDS row), full tiles, 16-byte aligned rows (checked by the host).
-// GLDS == 2: the A tile as well (A stored [K][M] with unit M stride, ALAY == 1, M == BM: one 1 KiB piece per k-row).
+// GLDS == 2: the A tile as well (A stored [K][M] with unit M stride, ALAY == 1: one 1 KiB piece per k-row for the
+// first 128 columns, plus a masked tail piece when 128 < M <= BM = 136; rows of the tile beyond M keep stale LDS
+// contents, which only reach output rows that are never stored).
+// With BLAY == 1 (B stored [N][K], unit K stride: a tile row is 16 doubles = 128 bytes) one piece covers 8 tile rows, so
+// the LDS image cannot be padded; it is [BN][16] with the eight 16-byte chunks of row n stored at chunk ^ ((n >> 1) & 7)
+// (applied to the per-lane SOURCE address), which keeps the 4 x 16 fragment reads at the two-pass minimum.
 template <int ALAY, int BLAY, int BM, int BN, int BK, int WM, int WN, int VEC, int ORIENT, int GLDS = 0>
 __global__ __launch_bounds__(WM *WN * 64) void k_gemm_f64q(GemmArgs<double> g) {
     typedef double T;
@@ -309,8 +314,10 @@ __global__ __launch_bounds__(WM *WN * 64) void k_gemm_f64q(GemmArgs<double> g) {
     static_assert(ORIENT == 0 ? (WR % 4 == 0 && WC % 16 == 0) : (WR % 16 == 0 && WC % 4 == 0), "wave tile shape");
     typedef TileStager<T, ALAY, BM, BK, NT, VEC> StA;
     typedef TileStager<T, BLAY == 1 ? 0 : 1, BN, BK, NT, VEC> StB;
-    constexpr int PA = StA::P, PB = StB::P;
-    constexpr int A_ELEMS = StA::ELEMS, B_ELEMS = StB::ELEMS;
+    constexpr bool SWZ = GLDS != 0 && BLAY == 1;  // swizzled, unpadded B image (see above)
+    constexpr int PA = StA::P, PB = SWZ ? BK : StB::P;
+    constexpr int A_ELEMS = StA::ELEMS, B_ELEMS = SWZ ? BN * BK : StB::ELEMS;
+    static_assert(!SWZ || BK == 16, "swizzled B image: 16-deep tiles");
 
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     T *smem = reinterpret_cast<T *>(smem_raw);
@@ -345,10 +352,24 @@ __global__ __launch_bounds__(WM *WN * 64) void k_gemm_f64q(GemmArgs<double> g) {
     StB sb;
     if (GLDS < 2) sa.init(g.a, m0, kbeg, g.sam, g.sak, tid);
     if (!GLDS) sb.init(g.b, n0, kbeg, g.sbn, g.sbk, tid);
-    static_assert(!GLDS || (BLAY == 0 && BN % 128 == 0 && (BK * (BN / 128)) % (NT / 64) == 0), "direct-to-LDS B tile: shape");
-    static_assert(GLDS < 2 || (ALAY == 1 && BM == 128 && BK % (NT / 64) == 0), "direct-to-LDS A tile: shape");
+    static_assert(!GLDS || BLAY == 1 || (BN % 128 == 0 && (BK * (BN / 128)) % (NT / 64) == 0), "direct-to-LDS B tile: shape");
+    static_assert(!GLDS || BLAY == 0 || (BN / 8) % (NT / 64) == 0, "direct-to-LDS B tile (K-contiguous): shape");
+    static_assert(GLDS < 2 || (ALAY == 1 && BM >= 128 && BM <= 256 && BK % (NT / 64) == 0), "direct-to-LDS A tile: shape");
     const int wave_u = __builtin_amdgcn_readfirstlane(wave);
     auto glds_b = [&](int64_t k0, T *bdst) {
+        if constexpr (BLAY == 1) {
+            constexpr int PER_WAVE = (BN / 8) / (NT / 64) > 0 ? (BN / 8) / (NT / 64) : 1;
+#pragma unroll
+            for (int i = 0; i < PER_WAVE; ++i) {
+                const int nb = (wave_u * PER_WAVE + i) * 8;         // eight tile rows per 1 KiB piece
+                const int nrow = nb + (lane >> 3);
+                const int chunk = (lane & 7) ^ ((nrow >> 1) & 7);    // source chunk that lands at position lane & 7
+                const T *src = g.b + (n0 + nrow) * g.sbn + (k0 + 2 * chunk);
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
+                                                 (__attribute__((address_space(3))) void *)(bdst + nb * BK), 16, 0, 0);
+            }
+            return;
+        }
         constexpr int PIECES_ROW = BN >= 128 ? BN / 128 : 1, PER_WAVE = BK * PIECES_ROW / (NT / 64) > 0 ? BK * PIECES_ROW / (NT / 64) : 1;
 #pragma unroll
         for (int i = 0; i < PER_WAVE; ++i) {
@@ -360,6 +381,7 @@ __global__ __launch_bounds__(WM *WN * 64) void k_gemm_f64q(GemmArgs<double> g) {
         }
     };
 
+    const int tail_lanes = (int)((g.M - m0 > 128 ? g.M - m0 - 128 : 0) + 1) / 2;
     auto glds_a = [&](int64_t k0, T *adst) {
         constexpr int PER_WAVE = BK / (NT / 64) > 0 ? BK / (NT / 64) : 1;
 #pragma unroll
@@ -368,6 +390,12 @@ __global__ __launch_bounds__(WM *WN * 64) void k_gemm_f64q(GemmArgs<double> g) {
             const T *src = g.a + (k0 + kk) * g.sak + (m0 + 2 * lane);
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
                                              (__attribute__((address_space(3))) void *)(adst + kk * PA), 16, 0, 0);
+            if constexpr (BM > 128) {
+                // columns 128 ... M - 1 (rounded up to a pair: the host checked that the pair stays inside the row)
+                if (lane < tail_lanes)
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + 128),
+                                                     (__attribute__((address_space(3))) void *)(adst + kk * PA + 128), 16, 0, 0);
+            }
         }
     };
 
@@ -407,7 +435,8 @@ __global__ __launch_bounds__(WM *WN * 64) void k_gemm_f64q(GemmArgs<double> g) {
 #pragma unroll
             for (int j = 0; j < TN; ++j) {
                 const int nn = wn * WC + j * BNW + lbn;
-                bf[j] = BLAY == 1 ? bs[nn * PB + kk] : bs[kk * PB + nn];
+                if (SWZ) bf[j] = bs[nn * BK + ((((kk >> 1) ^ ((nn >> 1) & 7)) << 1) | (kk & 1))];
+                else bf[j] = BLAY == 1 ? bs[nn * PB + kk] : bs[kk * PB + nn];
             }
         };
         {
@@ -536,7 +565,7 @@ static void launch_f64q(rc_context *c, GemmArgs<double> g) {
     constexpr int NT = WM * WN * 64;
     typedef TileStager<T, ALAY, BM, BK, NT, VEC> StA;
     typedef TileStager<T, BLAY == 1 ? 0 : 1, BN, BK, NT, VEC> StB;
-    constexpr size_t lds = 2 * (size_t)(StA::ELEMS + StB::ELEMS) * sizeof(T);
+    constexpr size_t lds = 2 * (size_t)(StA::ELEMS + (GLDS != 0 && BLAY == 1 ? BN * BK : StB::ELEMS)) * sizeof(T);
     static_assert(lds <= 160 * 1024, "tile does not fit LDS");
     g.tiles_m = (int)cdiv(g.M, BM);
     g.tiles_n = (int)cdiv(g.N, BN);
@@ -603,7 +632,19 @@ static bool launch_shape_f64q(rc_context *c, const GemmArgs<double> &g) {
         }
         launch_f64q<ALAY, BLAY, 128, 256, 16, 1, 8, VEC, 1>(c, g);
     }
-    else if (g.M <= 136 && vm == 3) launch_f64q<ALAY, BLAY, 136, 256, 16, 2, 4, VEC, 0>(c, g);  // 68 x 64 wave tiles: 17 + 4 fragment reads per 68 MFMAs
+    else if (g.M <= 136 && vm == 3) {  // 68 x 64 wave tiles: 17 + 4 fragment reads per 68 MFMAs
+        static const int glds = env_int("RC_GEMM_GLDS", 2);
+        if constexpr (ALAY == 1 && BLAY == 1 && VEC == 2) {
+            // the sketch (as the transposed problem): A' = Omega^T rows of M doubles, B' = A^T with unit K stride
+            const bool direct = glds >= 2 && g.M > 128 && g.N % 256 == 0 && g.K % 16 == 0 && g.sbk == 1 && g.sbn % 2 == 0 &&
+                                reinterpret_cast<uintptr_t>(g.b) % 16 == 0 && g.sam == 1 && g.sak % 2 == 0 && g.sak >= 128 + 2 * ((g.M - 128 + 1) / 2) &&
+                                reinterpret_cast<uintptr_t>(g.a) % 16 == 0;
+            static const int gs = env_int("RC_GEMM_GLDS_SKETCH", 0);  // measured: 1 (B direct) and 2 (A and B direct) are 1-2 % slower here
+            if (direct && gs == 2) { launch_f64q<ALAY, BLAY, 136, 256, 16, 2, 4, VEC, 0, 2>(c, g); return true; }
+            if (direct && gs == 1) { launch_f64q<ALAY, BLAY, 136, 256, 16, 2, 4, VEC, 0, 1>(c, g); return true; }
+        }
+        launch_f64q<ALAY, BLAY, 136, 256, 16, 2, 4, VEC, 0>(c, g);
+    }
     else if (g.M <= 144) {
         if (vm == 1) launch_f64q<ALAY, BLAY, 144, 128, 16, 1, 8, VEC, 1>(c, g);
         else if (vm == 2) launch_f64q<ALAY, BLAY, 144, 128, 16, 1, 4, VEC, 1>(c, g);
