@@ -303,6 +303,8 @@ __device__ unsigned long long g_gemm_dbg[8];
 // With BLAY == 1 (B stored [N][K], unit K stride: a tile row is 16 doubles = 128 bytes) one piece covers 8 tile rows, so
 // the LDS image cannot be padded; it is [BN][16] with the eight 16-byte chunks of row n stored at chunk ^ ((n >> 1) & 7)
 // (applied to the per-lane SOURCE address), which keeps the 4 x 16 fragment reads at the two-pass minimum.
+// GLDS == 3: as 2 with THREE LDS buffers: the copies of tile it + 2 are issued before tile it is computed and stay in
+// flight across the barrier (counted s_waitcnt vmcnt, raw LDS-only barrier), so no wave waits for HBM at the barrier.
 template <int ALAY, int BLAY, int BM, int BN, int BK, int WM, int WN, int VEC, int ORIENT, int GLDS = 0>
 __global__ __launch_bounds__(WM *WN * 64) void k_gemm_f64q(GemmArgs<double> g) {
     typedef double T;
@@ -401,24 +403,47 @@ __global__ __launch_bounds__(WM *WN * 64) void k_gemm_f64q(GemmArgs<double> g) {
 
     const int64_t nk = kend > kbeg ? cdiv(kend - kbeg, BK) : 0;
     if (nk > 0) {
-        if (GLDS == 2) glds_a(kbeg, smem);
+        if (GLDS >= 2) glds_a(kbeg, smem);
         else sa.load(m0, g.M, kbeg, kend, 0, g.sam, g.sak, tid);
         if (GLDS) glds_b(kbeg, smem + A_ELEMS);
         else sb.load(n0, g.N, kbeg, kend, 0, g.sbn, g.sbk, tid);
         if (GLDS < 2) sa.store(smem, tid);
         if (!GLDS) sb.store(smem + A_ELEMS, tid);
     }
-    __syncthreads();
+    // copies per wave and tile (GLDS == 3 counts them in s_waitcnt vmcnt)
+    constexpr int GL_PER_TILE = (BK / (NT / 64) > 0 ? BK / (NT / 64) : 1) * (BM > 128 ? 2 : 1) + (BLAY == 1 ? (BN / 8) / (NT / 64) : BK * (BN >= 128 ? BN / 128 : 1) / (NT / 64));
+    if constexpr (GLDS == 3) {
+        static_assert(BM <= 128, "counted waits assume no masked tail piece");
+        if (nk > 1) {
+            glds_a(kbeg + BK, smem + STAGE);
+            glds_b(kbeg + BK, smem + A_ELEMS + STAGE);
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(GL_PER_TILE) : "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    } else {
+        __syncthreads();
+    }
     constexpr int AM = ORIENT == 0 ? 4 : 16, BNW = ORIENT == 0 ? 16 : 4;
 #ifdef RC_GEMM_TIMING
     unsigned long long tacc[5] = {0, 0, 0, 0, 0}, tlast;
     asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tlast)::"memory");
 #endif
+    int buf3 = 0;  // GLDS == 3: it % 3
     for (int64_t it = 0; it < nk; ++it) {
-        const int buf = (int)(it & 1);
+        const int buf = GLDS == 3 ? buf3 : (int)(it & 1);
+        if constexpr (GLDS == 3) {
+            if (it + 2 < nk) {
+                const int nb = buf3 == 0 ? 2 : buf3 - 1;  // (it + 2) % 3: the buffer read in tile it - 1
+                const int64_t koff = (it + 2) * BK;
+                glds_a(kbeg + koff, smem + nb * STAGE);
+                glds_b(kbeg + koff, smem + A_ELEMS + nb * STAGE);
+            }
+        } else
         if (it + 1 < nk) {
             const int64_t koff = (it + 1) * BK;
-            if (GLDS == 2) glds_a(kbeg + koff, smem + (buf ^ 1) * STAGE);
+            if (GLDS >= 2) glds_a(kbeg + koff, smem + (buf ^ 1) * STAGE);
             else sa.load(m0, g.M, kbeg + koff, kend, koff * g.sak, g.sam, g.sak, tid);
             if (GLDS) glds_b(kbeg + koff, smem + A_ELEMS + (buf ^ 1) * STAGE);  // that buffer was last read in tile it - 1
             else sb.load(n0, g.N, kbeg + koff, kend, koff * g.sbk, g.sbn, g.sbk, tid);
@@ -456,12 +481,21 @@ __global__ __launch_bounds__(WM *WN * 64) void k_gemm_f64q(GemmArgs<double> g) {
             RC_STAMP(2)
         }
         }
-        if (it + 1 < nk) {
-            if (GLDS < 2) sa.store(smem + (buf ^ 1) * STAGE, tid);
-            if (!GLDS) sb.store(smem + A_ELEMS + (buf ^ 1) * STAGE, tid);
+        if constexpr (GLDS == 3) {
+            // tile it + 1 must have landed; the copies of tile it + 2 (issued above) stay in flight
+            if (it + 2 < nk) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(GL_PER_TILE) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            RC_STAMP(3)
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            buf3 = buf3 == 2 ? 0 : buf3 + 1;
+        } else {
+            if (it + 1 < nk) {
+                if (GLDS < 2) sa.store(smem + (buf ^ 1) * STAGE, tid);
+                if (!GLDS) sb.store(smem + A_ELEMS + (buf ^ 1) * STAGE, tid);
+            }
+            RC_STAMP(3)
+            __syncthreads();
         }
-        RC_STAMP(3)
-        __syncthreads();
         RC_STAMP(4)
     }
 #ifdef RC_GEMM_TIMING
@@ -565,7 +599,7 @@ static void launch_f64q(rc_context *c, GemmArgs<double> g) {
     constexpr int NT = WM * WN * 64;
     typedef TileStager<T, ALAY, BM, BK, NT, VEC> StA;
     typedef TileStager<T, BLAY == 1 ? 0 : 1, BN, BK, NT, VEC> StB;
-    constexpr size_t lds = 2 * (size_t)(StA::ELEMS + (GLDS != 0 && BLAY == 1 ? BN * BK : StB::ELEMS)) * sizeof(T);
+    constexpr size_t lds = (GLDS == 3 ? 3 : 2) * (size_t)(StA::ELEMS + (GLDS != 0 && BLAY == 1 ? BN * BK : StB::ELEMS)) * sizeof(T);
     static_assert(lds <= 160 * 1024, "tile does not fit LDS");
     g.tiles_m = (int)cdiv(g.M, BM);
     g.tiles_n = (int)cdiv(g.N, BN);
@@ -620,12 +654,13 @@ static bool launch_shape_f64q(rc_context *c, const GemmArgs<double> &g) {
     }
     else if (g.M <= 80) launch_f64q<ALAY, BLAY, 80, 256, 16, 1, 8, VEC, 1>(c, g);
     else if (g.M <= 128 && vm == 3) {
-        static const int glds = env_int("RC_GEMM_GLDS", 2);  // 0: register staging, 1: B tile direct to LDS, 2: A tile too
+        static const int glds = env_int("RC_GEMM_GLDS", 2);  // 0: register staging, 1: B tile direct to LDS, 2: A tile too, 3: + three LDS buffers (no gain measured)
         const bool direct = glds && BLAY == 0 && VEC == 2 && g.N % 256 == 0 && g.K % 16 == 0 && g.sbn == 1 && g.sbk % 2 == 0 &&
                             reinterpret_cast<uintptr_t>(g.b) % 16 == 0;
         if constexpr (BLAY == 0 && VEC == 2) {
             if constexpr (ALAY == 1) {
                 const bool direct_a = glds >= 2 && g.M == 128 && g.sam == 1 && g.sak % 2 == 0 && reinterpret_cast<uintptr_t>(g.a) % 16 == 0;
+                if (direct && direct_a && glds >= 3) { launch_f64q<ALAY, BLAY, 128, 256, 16, 1, 8, VEC, 1, 3>(c, g); return true; }
                 if (direct && direct_a) { launch_f64q<ALAY, BLAY, 128, 256, 16, 1, 8, VEC, 1, 2>(c, g); return true; }
             }
             if (direct) { launch_f64q<ALAY, BLAY, 128, 256, 16, 1, 8, VEC, 1, 1>(c, g); return true; }
