@@ -342,8 +342,3 @@ def main():
 
 if __name__ == "__main__":
     main()
-    # everything is destroyed and the line is printed: leave without the HIP runtime's exit-time teardown (a rare
-    # crash there -- seen once in a C++ client of the same library -- would turn a finished run into a failed one)
-    sys.stdout.flush()
-    sys.stderr.flush()
-    os._exit(0)
