@@ -105,10 +105,22 @@ __global__ __launch_bounds__(LPP == 16 ? 1024 : 512) void k_jacobi_lds(Mat<T> g,
     for (; sweep < max_sweeps; ++sweep) {
         if (tid == 0) sh_rot = 0;
         __syncthreads();
+        // circle-method pair of this group, advanced round by round when the group owns one pair slot (no integer
+        // modulo on the per-round critical path): slot 0 pairs N - 1 with r, slot pi pairs (r + pi) with (r - pi) mod N - 1
+        const bool one_slot = npairs <= ngrp;
+        int pr = grp % (N - 1), qr = ((N - 1) - grp % (N - 1)) % (N - 1);
         for (int r = 0; r < N - 1; ++r) {
             for (int pi = grp; pi < npairs; pi += ngrp) {
                 int p, q;
-                rr_pair(N, r, pi, p, q);
+                if (one_slot) {
+                    p = grp == 0 ? N - 1 : pr;
+                    q = grp == 0 ? pr : qr;
+                    if (p > q) { const int t = p; p = q; q = t; }
+                    pr = pr + 1 == N - 1 ? 0 : pr + 1;
+                    qr = qr + 1 == N - 1 ? 0 : qr + 1;
+                } else {
+                    rr_pair(N, r, pi, p, q);
+                }
                 Rot<T> rot{(T)1, (T)0};
                 if (q < n) {  // p < q; q == n is the dummy column of an odd n
                     T *gp = G + p * ld, *gq = G + q * ld;
@@ -429,7 +441,8 @@ void jacobi_svd(rc_context *c, Mat<T> g, Mat<T> vwork, Mat<T> uc, T *s, Mat<T> v
     const int n = (int)g.rows;
     if (n == 0) return;
     ProfScope ps(c, "op:jacobi_svd n=%lld", (long long)g.rows);
-    const int max_sweeps = 30;
+    static const int max_sweeps_env = [] { const char *e = getenv("RC_JACOBI_MAX_SWEEPS"); return e ? atoi(e) : 30; }();  // experiments only
+    const int max_sweeps = max_sweeps_env;
     const size_t lds = ((size_t)(n | 1) * n + n) * sizeof(T) + (size_t)n * sizeof(int) + 64;
     if (lds <= 160 * 1024 - 2048 - 64 && n <= 192) {
         static const int lpp = [] { const char *e = getenv("RC_JACOBI_LPP"); return e ? atoi(e) : 16; }();
