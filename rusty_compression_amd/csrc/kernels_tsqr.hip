@@ -278,10 +278,10 @@ __device__ inline T safe_hypot(T a, T b) {  // ?lapy2
 template <typename T>
 __device__ inline T fast_sqrt_pos(T x) { return x > (T)0 ? x * fast_rsqrt(x) : (T)0; }
 
-template <typename T, int NE>
-__global__ __launch_bounds__(512) void k_qrcp_small(Mat<T> rin, int kmax, int pivot, int64_t *jpvt_out, Mat<T> rout, Mat<T> q2) {
+template <typename T, int NE, int NTHR>
+__global__ __launch_bounds__(NTHR) void k_qrcp_small(Mat<T> rin, int kmax, int pivot, int64_t *jpvt_out, Mat<T> rout, Mat<T> q2) {
     constexpr int LPP = 8;     // lanes per column in the update
-    constexpr int NTHR = 512;  // 8 waves, 64 column groups
+    // NTHR threads = NTHR / 8 column groups: 1024 (n <= 144) covers the trailing columns of a step in one or two passes
     constexpr int NGRP = NTHR / LPP;
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     const int n = (int)rin.rows;
@@ -444,19 +444,21 @@ void qrcp_small(rc_context *c, Mat<T> rin, int64_t kmax, bool pivot, int64_t *jp
     const size_t lds = ((size_t)n * (n | 1) + 3 * (size_t)n) * sizeof(T) + (size_t)n * sizeof(int) + 64;
     RC_REQUIRE(lds <= 160 * 1024 - 1024 && n <= 208, RC_INVALID_ARGUMENT, "qrcp_small: n = %lld does not fit LDS", (long long)n);
     ProfScope ps(c, "op:qrcp_small n=%lld k=%lld", (long long)n, (long long)kmax);
-#define RC_QS(NE)                                                                                                      \
+#define RC_QS(NE, NT_)                                                                                                 \
     do {                                                                                                               \
-        auto kern = k_qrcp_small<T, NE>;                                                                               \
+        auto kern = k_qrcp_small<T, NE, NT_>;                                                                          \
         static bool attr_set[64] = {};                                                                                 \
         if (!attr_set[c->device & 63]) {                                                                               \
             RC_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024)); \
             attr_set[c->device & 63] = true;                                                                           \
         }                                                                                                              \
-        hipLaunchKernelGGL(kern, dim3(1), dim3(512), lds, c->stream, rin, (int)kmax, pivot ? 1 : 0, jpvt, rout, q2);   \
+        hipLaunchKernelGGL(kern, dim3(1), dim3(NT_), lds, c->stream, rin, (int)kmax, pivot ? 1 : 0, jpvt, rout, q2);   \
     } while (0)
-    if (n <= 64) RC_QS(8);
-    else if (n <= 144) RC_QS(18);
-    else RC_QS(26);
+    static const int wide = [] { const char *e = getenv("RC_QRCP_SMALL_1024"); return e ? atoi(e) : 1; }();
+    if (n <= 64) RC_QS(8, 512);
+    else if (n <= 144 && wide) RC_QS(18, 1024);
+    else if (n <= 144) RC_QS(18, 512);
+    else RC_QS(26, 512);
 #undef RC_QS
 }
 
