@@ -67,6 +67,43 @@ __device__ inline void jacobi_rotation(T app, T aqq, T apq, T &c, T &s) {
 // one rotation record of the log
 template <typename T> struct Rot { T c, s; };
 
+// Fused right-vector accumulation (second workgroup of k_jacobi_lds): the records travel from the producer to the
+// consumer workgroup through agent-scope atomics and the producer never waits for its stores.  Every record has a
+// check word hash(c, s) ^ magic ^ f(epoch); the epoch is a per-context device counter that both workgroups read at
+// their start and the consumer bumps at its end, so a torn combination, or a complete record of an EARLIER launch
+// that still sits at the same workspace address, never validates -- nothing has to be cleared before a launch.
+#define RC_AGENT __HIP_MEMORY_SCOPE_AGENT
+constexpr unsigned long long kRotMagic = 0x9e3779b97f4a7c15ull;
+__device__ inline unsigned long long rot_hash(Rot<double> r) { return (unsigned long long)__double_as_longlong(r.c) ^ ((unsigned long long)__double_as_longlong(r.s) * 3ull); }
+__device__ inline unsigned long long rot_hash(Rot<float> r) { return ((unsigned long long)__float_as_uint(r.s) << 32) | __float_as_uint(r.c); }
+__device__ inline unsigned long long epoch_key(unsigned e) { return kRotMagic ^ ((unsigned long long)e * 0xd1342543de82ef95ull); }
+__device__ inline void rot_publish(Rot<double> *p, unsigned long long *chk, Rot<double> r, unsigned long long key) {
+    __hip_atomic_store(&p->c, r.c, __ATOMIC_RELAXED, RC_AGENT);
+    __hip_atomic_store(&p->s, r.s, __ATOMIC_RELAXED, RC_AGENT);
+    __hip_atomic_store(chk, rot_hash(r) ^ key, __ATOMIC_RELAXED, RC_AGENT);
+}
+__device__ inline void rot_publish(Rot<float> *p, unsigned long long *chk, Rot<float> r, unsigned long long key) {
+    __hip_atomic_store(reinterpret_cast<unsigned long long *>(p), rot_hash(r), __ATOMIC_RELAXED, RC_AGENT);
+    __hip_atomic_store(chk, rot_hash(r) ^ key, __ATOMIC_RELAXED, RC_AGENT);
+}
+__device__ inline bool rot_fetch(const Rot<double> *p, const unsigned long long *chk, Rot<double> &r, unsigned long long key) {
+    r.c = __hip_atomic_load(&p->c, __ATOMIC_RELAXED, RC_AGENT);
+    r.s = __hip_atomic_load(&p->s, __ATOMIC_RELAXED, RC_AGENT);
+    return __hip_atomic_load(chk, __ATOMIC_RELAXED, RC_AGENT) == (rot_hash(r) ^ key);
+}
+__device__ inline bool rot_fetch(const Rot<float> *p, const unsigned long long *chk, Rot<float> &r, unsigned long long key) {
+    const unsigned long long w = __hip_atomic_load(reinterpret_cast<const unsigned long long *>(p), __ATOMIC_RELAXED, RC_AGENT);
+    r.c = __uint_as_float((unsigned)w);
+    r.s = __uint_as_float((unsigned)(w >> 32));
+    return __hip_atomic_load(chk, __ATOMIC_RELAXED, RC_AGENT) == (w ^ key);
+}
+// small integers (sweep count, sorted position + 1) travel as (epoch << 8) | payload
+__device__ inline void tagged_put(unsigned *p, unsigned e, unsigned payload) { __hip_atomic_store(p, (e << 8) | payload, __ATOMIC_RELAXED, RC_AGENT); }
+__device__ inline unsigned tagged_get(const unsigned *p, unsigned e) {  // 0 = not there yet
+    const unsigned w = __hip_atomic_load(p, __ATOMIC_RELAXED, RC_AGENT);
+    return (w >> 8) == (e & 0xffffffu) ? (w & 0xffu) : 0u;
+}
+
 // ---------------------------------------------------------------------------
 // LDS-resident one-sided Jacobi.  LPP lanes own one column pair and keep NE = ceil(n / LPP)
 // rows of both columns in registers; with LPP = 4 a 128 x 128 core needs only 4 waves
@@ -78,8 +115,11 @@ template <typename T> struct Rot { T c, s; };
 //   uc, s  : left singular vectors / singular values, sorted descending
 //   order  : order[j] = sorted position of original column j (for the V replay)
 // ---------------------------------------------------------------------------
+//   fused  : != 0: launched with TWO workgroups; the second one accumulates V from the published records while the first
+//            is still rotating (vsync[0] = number of sweeps once known, vsync[1 + j] = order[j] + 1; both zeroed before)
 template <typename T, int LPP, int NE>
-__global__ __launch_bounds__(LPP == 16 ? 1024 : 512) void k_jacobi_lds(Mat<T> g, Rot<T> *log, int *sweeps_out, Mat<T> uc, T *s, int *order_out, int max_sweeps) {
+__global__ __launch_bounds__(LPP == 16 ? 1024 : 512) void k_jacobi_lds(Mat<T> g, Rot<T> *log, int *sweeps_out, Mat<T> uc, T *s, int *order_out, int max_sweeps,
+                                                                       int fused, unsigned *vsync, unsigned long long *chk, unsigned *epoch_p, Mat<T> vc, int *health) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     const int n = (int)g.rows;
     const int ld = n | 1;  // odd pitch: column starts spread over all banks
@@ -92,6 +132,75 @@ __global__ __launch_bounds__(LPP == 16 ? 1024 : 512) void k_jacobi_lds(Mat<T> g,
     const int ll = tid % LPP, grp = tid / LPP, ngrp = nthr / LPP;
     const int N = (n + 1) & ~1;
     const int npairs = N / 2;
+    const unsigned epoch = fused ? __hip_atomic_load(epoch_p, __ATOMIC_RELAXED, RC_AGENT) & 0xffffffu : 0u;
+    const unsigned long long key = epoch_key(epoch);
+    if (fused && blockIdx.x == 1) {
+        // ---- consumer: V = product of the rotations, columns in LDS, the producer's pairing (one slot per group) ----
+        constexpr int kSpin = 1 << 24;
+        T *V = G;
+        for (int e = tid; e < n * n; e += nthr) {
+            const int i = e % n, j = e / n;
+            V[j * ld + i] = (i == j) ? (T)1 : (T)0;
+        }
+        __syncthreads();
+        bool lost = false;
+        for (int sweep = 0;; ++sweep) {
+            if (tid == 0) {  // has the producer started this sweep, or did it finish before it?
+                int fin = 2;
+                for (int it = 0; it < kSpin; ++it) {
+                    const unsigned d = tagged_get(vsync, epoch);
+                    if (d != 0u && (int)d <= sweep) { fin = 1; break; }
+                    Rot<T> r0;
+                    if (sweep < max_sweeps && rot_fetch(log + (size_t)sweep * (N - 1) * npairs, chk + (size_t)sweep * (N - 1) * npairs, r0, key)) { fin = 0; break; }
+                    __builtin_amdgcn_s_sleep(8);
+                }
+                sh_rot = fin;
+            }
+            __syncthreads();
+            const int fin = sh_rot;
+            __syncthreads();
+            if (fin) { lost = fin == 2; break; }
+            int pr = grp % (N - 1), qr = ((N - 1) - grp % (N - 1)) % (N - 1);
+            for (int r = 0; r < N - 1; ++r) {
+                if (grp < npairs) {
+                    int p = grp == 0 ? N - 1 : pr, q = grp == 0 ? pr : qr;
+                    if (p > q) { const int t = p; p = q; q = t; }
+                    pr = pr + 1 == N - 1 ? 0 : pr + 1;
+                    qr = qr + 1 == N - 1 ? 0 : qr + 1;
+                    Rot<T> rot{(T)1, (T)0};
+                    const size_t rec = ((size_t)sweep * (N - 1) + r) * npairs + grp;
+                    bool ok = false;
+                    for (int it = 0; it < kSpin && !(ok = rot_fetch(log + rec, chk + rec, rot, key)); ++it) __builtin_amdgcn_s_sleep(2);
+                    if (!ok) lost = true;
+                    if (ok && q < n && rot.s != (T)0) {
+                        T *vp = V + p * ld, *vq = V + q * ld;
+#pragma unroll
+                        for (int e = 0; e < NE; ++e) {
+                            const int i = ll + LPP * e;
+                            if (i < n) {
+                                const T a = vp[i], b = vq[i];
+                                vp[i] = rot.c * a - rot.s * b;
+                                vq[i] = rot.s * a + rot.c * b;
+                            }
+                        }
+                    }
+                }
+                lds_barrier();
+            }
+        }
+        // columns go out in the sorted order the producer publishes at its very end
+        for (int j = grp; j < n; j += ngrp) {
+            unsigned enc = 0;
+            for (int it = 0; it < kSpin && (enc = tagged_get(vsync + 1 + j, epoch)) == 0u; ++it) __builtin_amdgcn_s_sleep(8);
+            if (enc == 0u) { lost = true; continue; }
+            const int dst = (int)enc - 1;
+            for (int i = ll; i < n; i += LPP) vc.at(i, dst) = V[j * ld + i];
+        }
+        if (lost && ll == 0) atomicOr(health, 8);  // the producer never showed up within the spin bound: V is incomplete
+        __syncthreads();
+        if (tid == 0) __hip_atomic_fetch_add(epoch_p, 1u, __ATOMIC_RELAXED, RC_AGENT);  // the next launch uses a new key
+        return;
+    }
     const T tol = sqrt((T)n) * JEps<T>::eps();
     const T tol2 = tol * tol;
 
@@ -148,7 +257,10 @@ __global__ __launch_bounds__(LPP == 16 ? 1024 : 512) void k_jacobi_lds(Mat<T> g,
                         if (ll == 0) sh_rot = 1;
                     }
                 }
-                if (ll == 0) log[((size_t)sweep * (N - 1) + r) * npairs + pi] = rot;
+                if (ll == 0) {
+                    if (fused) rot_publish(log + ((size_t)sweep * (N - 1) + r) * npairs + pi, chk + ((size_t)sweep * (N - 1) + r) * npairs + pi, rot, key);
+                    else log[((size_t)sweep * (N - 1) + r) * npairs + pi] = rot;
+                }
             }
             lds_barrier();  // pairs of one round are disjoint; the next round re-pairs the columns
         }
@@ -156,7 +268,10 @@ __global__ __launch_bounds__(LPP == 16 ? 1024 : 512) void k_jacobi_lds(Mat<T> g,
         __syncthreads();
         if (!rotated) { ++sweep; break; }
     }
-    if (tid == 0) *sweeps_out = sweep;
+    if (tid == 0) {
+        *sweeps_out = sweep;
+        if (fused) tagged_put(vsync, epoch, (unsigned)sweep);
+    }
 
     // singular values = column norms; stable descending rank sort (gesdd order)
     for (int j = grp; j < n; j += ngrp) {
@@ -173,6 +288,7 @@ __global__ __launch_bounds__(LPP == 16 ? 1024 : 512) void k_jacobi_lds(Mat<T> g,
         for (int j = 0; j < n; ++j) rank += (sig[j] > si || (sig[j] == si && j < i)) ? 1 : 0;
         order[i] = rank;
         order_out[i] = rank;
+        if (fused) tagged_put(vsync + 1 + i, epoch, (unsigned)(rank + 1));
         s[rank] = si;
     }
     __syncthreads();
@@ -405,12 +521,24 @@ static void launch_lds(rc_context *c, Mat<T> g, Mat<T> uc, T *s, Mat<T> vc, size
     }
     // one LPP-lane group per pair, rounded up to whole waves
     const int threads = std::min(LPP == 16 ? 1024 : 512, std::max(64, (((N / 2) * LPP + 63) / 64) * 64));
-    hipLaunchKernelGGL(kern, dim3(1), dim3(threads), lds, c->stream, g, log, sweeps, uc, s, order, max_sweeps);
+    // fused right vectors: a second workgroup applies the rotations to V as they are published (no replay kernel
+    // after the fact); needs one pair slot per group and the padded n of the register tiling
+    static const int fuse_env = [] { const char *e = getenv("RC_JACOBI_FUSED_V"); return e ? atoi(e) : 1; }();
+    const bool fused = fuse_env && LPP == 16 && (N / 2) * LPP <= threads && n <= LPP * NE && n < 255 && max_sweeps < 255;
+    if (fused) {
+        unsigned *vsync = c->alloc<unsigned>((size_t)n + 1);
+        unsigned long long *chk = c->alloc<unsigned long long>((size_t)max_sweeps * (N - 1) * (N / 2));
+        hipLaunchKernelGGL(kern, dim3(2), dim3(threads), lds, c->stream, g, log, sweeps, uc, s, order, max_sweeps, 1, vsync, chk, c->epoch_word(), vc, c->health_word());
+    } else {
+        hipLaunchKernelGGL(kern, dim3(1), dim3(threads), lds, c->stream, g, log, sweeps, uc, s, order, max_sweeps, 0, (unsigned *)nullptr, (unsigned long long *)nullptr,
+                           (unsigned *)nullptr, vc, (int *)nullptr);
+    }
     static const int rpw_env = [] { const char *e = getenv("RC_REPLAY_RPW"); return e ? atoi(e) : 1; }();
     const int rpw = (N / 2 <= 64) ? (rpw_env == 2 || rpw_env == 4 ? rpw_env : 1) : 1;  // rows per wave: 1 measured best (913 vs 903 compressions/s at 4)
     const size_t lds_v = 4 * (size_t)rpw * (n + 1) * sizeof(T);
     const dim3 grid((unsigned)((n + 4 * rpw - 1) / (4 * rpw)));
-    if (rpw == 4) hipLaunchKernelGGL((k_jacobi_replay_v<T, 4>), grid, dim3(256), lds_v, c->stream, n, log, sweeps, order, vc);
+    if (fused) { /* V is already complete */ }
+    else if (rpw == 4) hipLaunchKernelGGL((k_jacobi_replay_v<T, 4>), grid, dim3(256), lds_v, c->stream, n, log, sweeps, order, vc);
     else if (rpw == 2) hipLaunchKernelGGL((k_jacobi_replay_v<T, 2>), grid, dim3(256), lds_v, c->stream, n, log, sweeps, order, vc);
     else hipLaunchKernelGGL((k_jacobi_replay_v<T, 1>), grid, dim3(256), lds_v, c->stream, n, log, sweeps, order, vc);
     if (c->prof_on && !c->capturing) {  // diagnostic: number of sweeps, reported through the profile table

@@ -112,10 +112,20 @@ int *rc_context::health_word() {
     return health;
 }
 
+unsigned *rc_context::epoch_word() {
+    if (!epoch) {
+        RC_HIP(hipMalloc(reinterpret_cast<void **>(&epoch), sizeof(unsigned)));
+        RC_HIP(hipMemset(epoch, 0, sizeof(unsigned)));
+    }
+    return epoch;
+}
+
 void rc_context::release_all() {
     (void)hipStreamSynchronize(stream);
     if (health) (void)hipFree(health);
     health = nullptr;
+    if (epoch) (void)hipFree(epoch);
+    epoch = nullptr;
     prof_resolve();
     for (hipEvent_t e : prof_free) (void)hipEventDestroy(e);
     prof_free.clear();
@@ -734,7 +744,7 @@ rc_status rc_create(rc_context **ctx, int32_t device, void *hip_stream) {
     c->stream = static_cast<hipStream_t>(hip_stream);
     {
         DeviceGuard dg(device);
-        try { (void)c->health_word(); coop_prepare(device); } catch (const Error &) { delete c; return RC_RUNTIME_ERROR; }
+        try { (void)c->health_word(); (void)c->epoch_word(); coop_prepare(device); } catch (const Error &) { delete c; return RC_RUNTIME_ERROR; }
     }
     *ctx = c;
     return RC_OK;

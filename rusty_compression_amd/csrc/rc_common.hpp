@@ -120,6 +120,8 @@ struct rc_context {
     int opt_wide_lazy = 1;  // short-wide pivoted QR through the read-only lazy scheme (0: eager Householder chain)
     int *health = nullptr;
     int *health_word();
+    unsigned *epoch = nullptr;  // launch counter of the fused Jacobi (keys its producer -> consumer records)
+    unsigned *epoch_word();
 
     // hipGraph capture state and the event-based stage/kernel timers (rc_profile_*)
     bool capturing = false;
