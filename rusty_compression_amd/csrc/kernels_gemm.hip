@@ -643,7 +643,7 @@ static bool launch_shape_f64q(rc_context *c, const GemmArgs<double> &g) {
     // Skinny shapes: the narrow dimension is padded to the micro-tile granularity only -- 16 along the
     // "shared" operand's side, 4 along the other (ORIENT picks which) -- so N = 133 costs 136, M = 128 costs 128.
     // (N = 133 through ORIENT 1 / BN = 136 measured slower than BN = 144: 34 B-fragment reads per sub-step.)
-    static const int vn = env_int("RC_GEMM_F64Q_N", 3), vm = env_int("RC_GEMM_F64Q_M", 3);
+    static const int vn = env_int("RC_GEMM_F64Q_N", 3), vm = env_int("RC_GEMM_F64Q_M", 3), smallk = env_int("RC_GEMM_SMALLK", 1);
     if (g.M <= 144 && g.N <= 144 && g.M > 80 && g.N > 80) launch_f64q<ALAY, BLAY, 144, 144, 16, 3, 3, VEC, 0>(c, g);
     else if (g.N <= 80) launch_f64q<ALAY, BLAY, 256, 80, 16, 8, 1, VEC, 0>(c, g);
     else if (g.N <= 128 && vn == 3) launch_f64q<ALAY, BLAY, 256, 128, 16, 8, 1, VEC, 0>(c, g);
@@ -653,6 +653,12 @@ static bool launch_shape_f64q(rc_context *c, const GemmArgs<double> &g) {
         else launch_f64q<ALAY, BLAY, 256, 144, 16, 8, 1, VEC, 0>(c, g);
     }
     else if (g.M <= 80) launch_f64q<ALAY, BLAY, 80, 256, 16, 1, 8, VEC, 1>(c, g);
+    else if (g.M <= 136 && g.K <= 160 && smallk && g.N >= 2048) {
+        // shallow products on the dependent chain of a compression (apply R^-1, Q1 Q2, Q U_b, ...: K = 128 / 133): 128-wide
+        // tiles = twice the workgroups of the 256-wide instance, for latency rather than efficiency
+        if (g.M <= 128) launch_f64q<ALAY, BLAY, 128, 128, 16, 1, 8, VEC, 1>(c, g);
+        else launch_f64q<ALAY, BLAY, 136, 128, 16, 2, 4, VEC, 0>(c, g);
+    }
     else if (g.M <= 128 && vm == 3) {
         static const int glds = env_int("RC_GEMM_GLDS", 2);  // 0: register staging, 1: B tile direct to LDS, 2: A tile too, 3: + three LDS buffers (no gain measured)
         const bool direct = glds && BLAY == 0 && VEC == 2 && g.N % 256 == 0 && g.K % 16 == 0 && g.sbn == 1 && g.sbk % 2 == 0 &&
