@@ -254,7 +254,10 @@ __global__ __launch_bounds__(LPP == 16 ? 1024 : 512) void k_jacobi_lds(Mat<T> g,
                                 gq[i] = rot.s * a[e] + rot.c * b[e];
                             }
                         }
-                        if (ll == 0) sh_rot = 1;
+                        // 1 = rotated; 2 = rotated by an angle with cos > sqrt(tol) / 4 (9e-9 in f64): only then is another
+                        // sweep needed -- the convergence is quadratic, smaller angles leave angles << tol behind, so the
+                        // sweep that finds nothing larger is the last one (no separate all-quiet verification sweep)
+                        if (ll == 0) atomicMax(const_cast<int *>(sh_rot_p), (apq * apq > tol * (T)0.0625 * app * aqq) ? 2 : 1);
                     }
                 }
                 if (ll == 0) {
@@ -266,7 +269,7 @@ __global__ __launch_bounds__(LPP == 16 ? 1024 : 512) void k_jacobi_lds(Mat<T> g,
         }
         const int rotated = sh_rot;
         __syncthreads();
-        if (!rotated) { ++sweep; break; }
+        if (rotated < 2) { ++sweep; break; }
     }
     if (tid == 0) {
         *sweeps_out = sweep;
