@@ -254,10 +254,10 @@ __global__ __launch_bounds__(LPP == 16 ? 1024 : 512) void k_jacobi_lds(Mat<T> g,
                                 gq[i] = rot.s * a[e] + rot.c * b[e];
                             }
                         }
-                        // 1 = rotated; 2 = rotated by an angle with cos > sqrt(tol) / 4 (9e-9 in f64): only then is another
+                        // flag 2 = some pair rotated by an angle with cos > sqrt(tol) / 4 (9e-9 in f64): only then is another
                         // sweep needed -- the convergence is quadratic, smaller angles leave angles << tol behind, so the
                         // sweep that finds nothing larger is the last one (no separate all-quiet verification sweep)
-                        if (ll == 0) atomicMax(const_cast<int *>(sh_rot_p), (apq * apq > tol * (T)0.0625 * app * aqq) ? 2 : 1);
+                        if (ll == 0 && apq * apq > tol * (T)0.0625 * app * aqq) sh_rot = 2;  // plain store: every writer writes 2
                     }
                 }
                 if (ll == 0) {
