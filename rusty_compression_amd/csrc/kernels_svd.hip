@@ -117,17 +117,26 @@ __device__ inline unsigned tagged_get(const unsigned *p, unsigned e) {  // 0 = n
 // ---------------------------------------------------------------------------
 //   fused  : != 0: launched with TWO workgroups; the second one accumulates V from the published records while the first
 //            is still rotating (vsync[0] = number of sweeps once known, vsync[1 + j] = order[j] + 1; both zeroed before)
-template <typename T, int LPP, int NE>
+// RC_JAC_ABL: timing ablations of the producer's round (diagnostic builds only, tools/jacobi_ablation.sh; results are WRONG):
+// 1 no rotation records, 2 no rcp/rsqrt in the rotation, 4 no write-back, 8 no group reduction, 16 no LDS reads, 32 rotate always
+#ifndef RC_JAC_ABL
+#define RC_JAC_ABL 0
+#endif
+//   FULL   : n == LPP * NE and one group per pair slot: no row / column bounds, no slot loop (the round is bound by the
+//            number of instructions the 16 waves issue, and the predicates were a quarter of them)
+template <typename T, int LPP, int NE, bool FULL>
 __global__ __launch_bounds__(LPP == 16 ? 1024 : 512) void k_jacobi_lds(Mat<T> g, Rot<T> *log, int *sweeps_out, Mat<T> uc, T *s, int *order_out, int max_sweeps,
-                                                                       int fused, unsigned *vsync, unsigned long long *chk, unsigned *epoch_p, Mat<T> vc, int *health) {
+                                                                       int fused, unsigned *vsync, unsigned long long *chk, unsigned *epoch_p, Mat<T> vc, int *health, int ld) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     const int n = (int)g.rows;
-    const int ld = n | 1;  // odd pitch: column starts spread over all banks
+    // ld: column pitch chosen by the host (jacobi_pitch): the two column groups of a 32-lane half read neighbouring columns
     T *G = reinterpret_cast<T *>(smem_raw);
     T *sig = G + (size_t)ld * n;
     int *order = reinterpret_cast<int *>(sig + n);
-    volatile int *sh_rot_p = order + n;  // all LDS in the one dynamic array (keeps its base aligned)
-#define sh_rot (*sh_rot_p)
+    // a static LDS word: behind a pointer into the dynamic array the compiler lost the address space and issued FLAT
+    // stores + s_waitcnt vmcnt(0) for it, which also waited for the rotation records in flight
+    __shared__ int sh_rot_word;
+#define sh_rot sh_rot_word
     const int tid = threadIdx.x, nthr = blockDim.x;
     const int ll = tid % LPP, grp = tid / LPP, ngrp = nthr / LPP;
     const int N = (n + 1) & ~1;
@@ -162,7 +171,7 @@ __global__ __launch_bounds__(LPP == 16 ? 1024 : 512) void k_jacobi_lds(Mat<T> g,
             if (fin) { lost = fin == 2; break; }
             int pr = grp % (N - 1), qr = ((N - 1) - grp % (N - 1)) % (N - 1);
             for (int r = 0; r < N - 1; ++r) {
-                if (grp < npairs) {
+                if (FULL || grp < npairs) {
                     int p = grp == 0 ? N - 1 : pr, q = grp == 0 ? pr : qr;
                     if (p > q) { const int t = p; p = q; q = t; }
                     pr = pr + 1 == N - 1 ? 0 : pr + 1;
@@ -172,12 +181,12 @@ __global__ __launch_bounds__(LPP == 16 ? 1024 : 512) void k_jacobi_lds(Mat<T> g,
                     bool ok = false;
                     for (int it = 0; it < kSpin && !(ok = rot_fetch(log + rec, chk + rec, rot, key)); ++it) __builtin_amdgcn_s_sleep(2);
                     if (!ok) lost = true;
-                    if (ok && q < n && rot.s != (T)0) {
+                    if (ok && (FULL || q < n) && rot.s != (T)0) {
                         T *vp = V + p * ld, *vq = V + q * ld;
 #pragma unroll
                         for (int e = 0; e < NE; ++e) {
                             const int i = ll + LPP * e;
-                            if (i < n) {
+                            if (FULL || i < n) {
                                 const T a = vp[i], b = vq[i];
                                 vp[i] = rot.c * a - rot.s * b;
                                 vq[i] = rot.s * a + rot.c * b;
@@ -216,10 +225,10 @@ __global__ __launch_bounds__(LPP == 16 ? 1024 : 512) void k_jacobi_lds(Mat<T> g,
         __syncthreads();
         // circle-method pair of this group, advanced round by round when the group owns one pair slot (no integer
         // modulo on the per-round critical path): slot 0 pairs N - 1 with r, slot pi pairs (r + pi) with (r - pi) mod N - 1
-        const bool one_slot = npairs <= ngrp;
+        const bool one_slot = FULL || npairs <= ngrp;
         int pr = grp % (N - 1), qr = ((N - 1) - grp % (N - 1)) % (N - 1);
         for (int r = 0; r < N - 1; ++r) {
-            for (int pi = grp; pi < npairs; pi += ngrp) {
+            for (int pi = grp; pi < npairs; pi += FULL ? (1 << 20) : ngrp) {  // FULL: exactly one trip
                 int p, q;
                 if (one_slot) {
                     p = grp == 0 ? N - 1 : pr;
@@ -231,25 +240,30 @@ __global__ __launch_bounds__(LPP == 16 ? 1024 : 512) void k_jacobi_lds(Mat<T> g,
                     rr_pair(N, r, pi, p, q);
                 }
                 Rot<T> rot{(T)1, (T)0};
-                if (q < n) {  // p < q; q == n is the dummy column of an odd n
+                if (FULL || q < n) {  // p < q; q == n is the dummy column of an odd n
                     T *gp = G + p * ld, *gq = G + q * ld;
                     T a[NE], b[NE];
                     T app = 0, aqq = 0, apq = 0;
 #pragma unroll
                     for (int e = 0; e < NE; ++e) {
                         int i = ll + LPP * e;
-                        a[e] = (i < n) ? gp[i] : (T)0;
-                        b[e] = (i < n) ? gq[i] : (T)0;
+                        if (RC_JAC_ABL & 16) { a[e] = (T)(i + p) * (T)1e-3; b[e] = (T)(i - q) * (T)1e-3; }
+                        else {
+                        a[e] = (FULL || i < n) ? gp[i] : (T)0;
+                        b[e] = (FULL || i < n) ? gq[i] : (T)0;
+                        }
                         app = fma(a[e], a[e], app); aqq = fma(b[e], b[e], aqq); apq = fma(a[e], b[e], apq);
                     }
-                    app = group_sum_dpp<LPP>(app); aqq = group_sum_dpp<LPP>(aqq); apq = group_sum_dpp<LPP>(apq);
+                    if (!(RC_JAC_ABL & 8)) { app = group_sum_dpp<LPP>(app); aqq = group_sum_dpp<LPP>(aqq); apq = group_sum_dpp<LPP>(apq); }
                     // rotate iff |apq| > tol * sqrt(app * aqq)   (uniform over the LPP lanes)
-                    if (apq * apq > tol2 * app * aqq) {
-                        jacobi_rotation(app, aqq, apq, rot.c, rot.s);
+                    if ((RC_JAC_ABL & 32) || apq * apq > tol2 * app * aqq) {
+                        if (RC_JAC_ABL & 2) { rot.c = (T)0.8 + apq * (T)1e-30; rot.s = (T)0.6 + app * (T)1e-30; }
+                        else jacobi_rotation(app, aqq, apq, rot.c, rot.s);
 #pragma unroll
                         for (int e = 0; e < NE; ++e) {
                             int i = ll + LPP * e;
-                            if (i < n) {
+                            if (RC_JAC_ABL & 4) { if (rot.c * a[e] - rot.s * b[e] == (T)123.456 && rot.s * a[e] + rot.c * b[e] == (T)654.321) gp[i] = 0; }
+                            else if (FULL || i < n) {
                                 gp[i] = rot.c * a[e] - rot.s * b[e];
                                 gq[i] = rot.s * a[e] + rot.c * b[e];
                             }
@@ -260,7 +274,7 @@ __global__ __launch_bounds__(LPP == 16 ? 1024 : 512) void k_jacobi_lds(Mat<T> g,
                         if (ll == 0 && apq * apq > tol * (T)0.0625 * app * aqq) sh_rot = 2;  // plain store: every writer writes 2
                     }
                 }
-                if (ll == 0) {
+                if (ll == 0 && !(RC_JAC_ABL & 1)) {
                     if (fused) rot_publish(log + ((size_t)sweep * (N - 1) + r) * npairs + pi, chk + ((size_t)sweep * (N - 1) + r) * npairs + pi, rot, key);
                     else log[((size_t)sweep * (N - 1) + r) * npairs + pi] = rot;
                 }
@@ -269,7 +283,7 @@ __global__ __launch_bounds__(LPP == 16 ? 1024 : 512) void k_jacobi_lds(Mat<T> g,
         }
         const int rotated = sh_rot;
         __syncthreads();
-        if (rotated < 2) { ++sweep; break; }
+        if (!(RC_JAC_ABL & 32) && rotated < 2) { ++sweep; break; }
     }
     if (tid == 0) {
         *sweeps_out = sweep;
@@ -509,14 +523,14 @@ static void jacobi_global(rc_context *c, Mat<T> g, Mat<T> v, Mat<T> uc, T *s, Ma
     hipLaunchKernelGGL(k_jacobi_emit<T>, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, c->stream, g, v, sig, order, uc, vc);
 }
 
-template <typename T, int LPP, int NE>
-static void launch_lds(rc_context *c, Mat<T> g, Mat<T> uc, T *s, Mat<T> vc, size_t lds, int max_sweeps) {
+template <typename T, int LPP, int NE, bool FULL>
+static void launch_lds_impl(rc_context *c, Mat<T> g, Mat<T> uc, T *s, Mat<T> vc, size_t lds, int ld, int max_sweeps) {
     const int n = (int)g.rows, N = (n + 1) & ~1;
     ArenaMark mark(c);
     Rot<T> *log = c->alloc<Rot<T>>((size_t)max_sweeps * (N - 1) * (N / 2));
     int *sweeps = c->alloc<int>(1);
     int *order = c->alloc<int>((size_t)n);
-    auto kern = k_jacobi_lds<T, LPP, NE>;
+    auto kern = k_jacobi_lds<T, LPP, NE, FULL>;
     static bool attr_set[64] = {};
     if (!attr_set[c->device & 63]) {
         RC_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 2048));
@@ -531,10 +545,10 @@ static void launch_lds(rc_context *c, Mat<T> g, Mat<T> uc, T *s, Mat<T> vc, size
     if (fused) {
         unsigned *vsync = c->alloc<unsigned>((size_t)n + 1);
         unsigned long long *chk = c->alloc<unsigned long long>((size_t)max_sweeps * (N - 1) * (N / 2));
-        hipLaunchKernelGGL(kern, dim3(2), dim3(threads), lds, c->stream, g, log, sweeps, uc, s, order, max_sweeps, 1, vsync, chk, c->epoch_word(), vc, c->health_word());
+        hipLaunchKernelGGL(kern, dim3(2), dim3(threads), lds, c->stream, g, log, sweeps, uc, s, order, max_sweeps, 1, vsync, chk, c->epoch_word(), vc, c->health_word(), ld);
     } else {
         hipLaunchKernelGGL(kern, dim3(1), dim3(threads), lds, c->stream, g, log, sweeps, uc, s, order, max_sweeps, 0, (unsigned *)nullptr, (unsigned long long *)nullptr,
-                           (unsigned *)nullptr, vc, (int *)nullptr);
+                           (unsigned *)nullptr, vc, (int *)nullptr, ld);
     }
     static const int rpw_env = [] { const char *e = getenv("RC_REPLAY_RPW"); return e ? atoi(e) : 1; }();
     const int rpw = (N / 2 <= 64) ? (rpw_env == 2 || rpw_env == 4 ? rpw_env : 1) : 1;  // rows per wave: 1 measured best (913 vs 903 compressions/s at 4)
@@ -556,14 +570,23 @@ static void launch_lds(rc_context *c, Mat<T> g, Mat<T> uc, T *s, Mat<T> vc, size
     }
 }
 
+template <typename T, int LPP, int NE>
+static void launch_lds(rc_context *c, Mat<T> g, Mat<T> uc, T *s, Mat<T> vc, size_t lds, int ld, int max_sweeps) {
+    // the bound-free instance: every lane row and every pair slot is real (n = 32, 64, 128 with 16 lanes per pair)
+    static const int full_env = [] { const char *e = getenv("RC_JACOBI_FULL"); return e ? atoi(e) : 1; }();
+    const int n = (int)g.rows;
+    if (full_env && LPP == 16 && n == LPP * NE && (n / 2) * LPP <= 1024) launch_lds_impl<T, LPP, NE, true>(c, g, uc, s, vc, lds, ld, max_sweeps);
+    else launch_lds_impl<T, LPP, NE, false>(c, g, uc, s, vc, lds, ld, max_sweeps);
+}
+
 template <typename T, int LPP>
-static void launch_lds_lpp(rc_context *c, Mat<T> g, Mat<T> uc, T *s, Mat<T> vc, size_t lds, int max_sweeps) {
+static void launch_lds_lpp(rc_context *c, Mat<T> g, Mat<T> uc, T *s, Mat<T> vc, size_t lds, int ld, int max_sweeps) {
     const int n = (int)g.rows;
     constexpr int U = 32 / LPP;  // rows per lane at n = 32
-    if (n <= 32) launch_lds<T, LPP, U>(c, g, uc, s, vc, lds, max_sweeps);
-    else if (n <= 64) launch_lds<T, LPP, 2 * U>(c, g, uc, s, vc, lds, max_sweeps);
-    else if (n <= 128) launch_lds<T, LPP, 4 * U>(c, g, uc, s, vc, lds, max_sweeps);
-    else launch_lds<T, LPP, 6 * U>(c, g, uc, s, vc, lds, max_sweeps);  // f32 up to n = 192 (the LDS bound is ~200)
+    if (n <= 32) launch_lds<T, LPP, U>(c, g, uc, s, vc, lds, ld, max_sweeps);
+    else if (n <= 64) launch_lds<T, LPP, 2 * U>(c, g, uc, s, vc, lds, ld, max_sweeps);
+    else if (n <= 128) launch_lds<T, LPP, 4 * U>(c, g, uc, s, vc, lds, ld, max_sweeps);
+    else launch_lds<T, LPP, 6 * U>(c, g, uc, s, vc, lds, ld, max_sweeps);  // f32 up to n = 192 (the LDS bound is ~200)
 }
 
 template <typename T>
@@ -574,12 +597,21 @@ void jacobi_svd(rc_context *c, Mat<T> g, Mat<T> vwork, Mat<T> uc, T *s, Mat<T> v
     ProfScope ps(c, "op:jacobi_svd n=%lld", (long long)g.rows);
     static const int max_sweeps_env = [] { const char *e = getenv("RC_JACOBI_MAX_SWEEPS"); return e ? atoi(e) : 30; }();  // experiments only
     const int max_sweeps = max_sweeps_env;
-    const size_t lds = ((size_t)(n | 1) * n + n) * sizeof(T) + (size_t)n * sizeof(int) + 64;
-    if (lds <= 160 * 1024 - 2048 - 64 && n <= 192) {
+    // Column pitch in LDS.  A 32-lane half of a wave holds the groups of two neighbouring pair slots, whose columns are
+    // neighbours too (p, p + 1 and q, q - 1): with a pitch of 16 elements modulo 32 the two 16-lane groups read opposite
+    // halves of the bank row (ds_read_b64: 64 banks, f32 ds_read_b32: 32 banks) -- conflict-free, where the odd pitch n | 1
+    // made every such read two-way conflicted.  The padded pitch is used whenever it fits the CU's LDS.
+    static const int pitch_env = [] { const char *e = getenv("RC_JACOBI_PITCH"); return e ? atoi(e) : 1; }();
+    const size_t lds_cap = 160 * 1024 - 2048 - 64;
+    auto lds_bytes = [&](int pitch) { return ((size_t)pitch * n + n) * sizeof(T) + (size_t)n * sizeof(int) + 64; };
+    int ld = ((n + 15) / 32) * 32 + 16;
+    if (!pitch_env || lds_bytes(ld) > lds_cap) ld = n | 1;
+    const size_t lds = lds_bytes(ld);
+    if (lds <= lds_cap && n <= 192) {
         static const int lpp = [] { const char *e = getenv("RC_JACOBI_LPP"); return e ? atoi(e) : 16; }();
-        if (lpp == 4) launch_lds_lpp<T, 4>(c, g, uc, s, vc, lds, max_sweeps);
-        else if (lpp == 8) launch_lds_lpp<T, 8>(c, g, uc, s, vc, lds, max_sweeps);
-        else launch_lds_lpp<T, 16>(c, g, uc, s, vc, lds, max_sweeps);
+        if (lpp == 4) launch_lds_lpp<T, 4>(c, g, uc, s, vc, lds, ld, max_sweeps);
+        else if (lpp == 8) launch_lds_lpp<T, 8>(c, g, uc, s, vc, lds, ld, max_sweeps);
+        else launch_lds_lpp<T, 16>(c, g, uc, s, vc, lds, ld, max_sweeps);
     } else {
         jacobi_global<T>(c, g, vwork, uc, s, vc);
     }
