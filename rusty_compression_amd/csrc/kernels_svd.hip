@@ -48,18 +48,23 @@ __device__ inline void rr_pair(int N, int r, int pi, int &p, int &q) {
     if (p > q) { int t = p; p = q; q = t; }
 }
 
-// Rotation that annihilates the (p, q) entry of the Gram matrix: t = sign(zeta) / (|zeta| + sqrt(1 + zeta^2)),
-// c = 1 / sqrt(1 + t^2), s = c t.  Always evaluated in f64: with f32 parameters c^2 + s^2 - 1 has a systematic
-// sign, and the thousands of rotations a column goes through inflate the singular values (3e-5 at n = 300).
-// A huge |zeta| (tiny angle) is safe: t -> 0.
+// Rotation that annihilates the (p, q) entry of the Gram matrix: with d = aqq - app, h = 2 apq (zeta = d / h)
+//   t = sign(zeta) / (|zeta| + sqrt(1 + zeta^2)) = sign(d h) |h| / (|d| + sqrt(d^2 + h^2)),   c = 1 / sqrt(1 + t^2),  s = c t
+// -- the second form has one reciprocal less on the round's dependent chain.  t only decides how completely the entry is
+// annihilated, so its reciprocal and root take ONE Newton step (1e-15); c decides the orthogonality of the rotation and keeps two.
+// Always evaluated in f64: with f32 parameters c^2 + s^2 - 1 has a systematic sign, and the thousands of rotations a
+// column goes through inflate the singular values (3e-5 at n = 300).  A tiny angle (|d| >> |h|) is safe: t -> 0.
 template <typename T>
 __device__ inline void jacobi_rotation(T app, T aqq, T apq, T &c, T &s) {
-    const double zeta = ((double)aqq - (double)app) * fast_rcp(2.0 * (double)apq);
-    const double az = fabs(zeta);
-    const double w = 1.0 + az * az;
-    const double root = (az < 1e18) ? w * fast_rsqrt(w) : az;
-    const double t = copysign(fast_rcp(az + root), zeta);
-    const double cd = fast_rsqrt(1.0 + t * t);
+    const double d = (double)aqq - (double)app, h = 2.0 * (double)apq;
+    const double w = fma(d, d, h * h);
+    double ri = __builtin_amdgcn_rsq(w);
+    ri = ri * fma(-0.5 * w, ri * ri, 1.5);
+    const double den = fabs(d) + w * ri;
+    double rd = __builtin_amdgcn_rcp(den);
+    rd = fma(fma(-den, rd, 1.0), rd, rd);
+    const double t = copysign(fabs(h) * rd, d * h);
+    const double cd = fast_rsqrt(fma(t, t, 1.0));
     c = (T)cd;
     s = (T)(cd * t);
 }
@@ -541,7 +546,7 @@ static void launch_lds_impl(rc_context *c, Mat<T> g, Mat<T> uc, T *s, Mat<T> vc,
     // fused right vectors: a second workgroup applies the rotations to V as they are published (no replay kernel
     // after the fact); needs one pair slot per group and the padded n of the register tiling
     static const int fuse_env = [] { const char *e = getenv("RC_JACOBI_FUSED_V"); return e ? atoi(e) : 1; }();
-    const bool fused = fuse_env && LPP == 16 && (N / 2) * LPP <= threads && n <= LPP * NE && n < 255 && max_sweeps < 255;
+    const bool fused = fuse_env && (LPP == 16 || LPP == 8) && (N / 2) * LPP <= threads && n <= LPP * NE && n < 255 && max_sweeps < 255;
     if (fused) {
         unsigned *vsync = c->alloc<unsigned>((size_t)n + 1);
         unsigned long long *chk = c->alloc<unsigned long long>((size_t)max_sweeps * (N - 1) * (N / 2));
@@ -575,7 +580,7 @@ static void launch_lds(rc_context *c, Mat<T> g, Mat<T> uc, T *s, Mat<T> vc, size
     // the bound-free instance: every lane row and every pair slot is real (n = 32, 64, 128 with 16 lanes per pair)
     static const int full_env = [] { const char *e = getenv("RC_JACOBI_FULL"); return e ? atoi(e) : 1; }();
     const int n = (int)g.rows;
-    if (full_env && LPP == 16 && n == LPP * NE && (n / 2) * LPP <= 1024) launch_lds_impl<T, LPP, NE, true>(c, g, uc, s, vc, lds, ld, max_sweeps);
+    if (full_env && (LPP == 16 || LPP == 8) && n == LPP * NE && (n / 2) * LPP <= (LPP == 16 ? 1024 : 512)) launch_lds_impl<T, LPP, NE, true>(c, g, uc, s, vc, lds, ld, max_sweeps);
     else launch_lds_impl<T, LPP, NE, false>(c, g, uc, s, vc, lds, ld, max_sweeps);
 }
 
@@ -604,11 +609,11 @@ void jacobi_svd(rc_context *c, Mat<T> g, Mat<T> vwork, Mat<T> uc, T *s, Mat<T> v
     static const int pitch_env = [] { const char *e = getenv("RC_JACOBI_PITCH"); return e ? atoi(e) : 1; }();
     const size_t lds_cap = 160 * 1024 - 2048 - 64;
     auto lds_bytes = [&](int pitch) { return ((size_t)pitch * n + n) * sizeof(T) + (size_t)n * sizeof(int) + 64; };
-    int ld = ((n + 15) / 32) * 32 + 16;
+    static const int lpp = [] { const char *e = getenv("RC_JACOBI_LPP"); return e ? atoi(e) : 16; }();
+    int ld = lpp == 8 ? ((n + 23) / 32) * 32 + 8 : ((n + 15) / 32) * 32 + 16;  // 8 lanes per pair: four groups per half, a quarter row apart
     if (!pitch_env || lds_bytes(ld) > lds_cap) ld = n | 1;
     const size_t lds = lds_bytes(ld);
     if (lds <= lds_cap && n <= 192) {
-        static const int lpp = [] { const char *e = getenv("RC_JACOBI_LPP"); return e ? atoi(e) : 16; }();
         if (lpp == 4) launch_lds_lpp<T, 4>(c, g, uc, s, vc, lds, ld, max_sweeps);
         else if (lpp == 8) launch_lds_lpp<T, 8>(c, g, uc, s, vc, lds, ld, max_sweeps);
         else launch_lds_lpp<T, 16>(c, g, uc, s, vc, lds, ld, max_sweeps);
