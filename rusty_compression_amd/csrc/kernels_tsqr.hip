@@ -484,8 +484,9 @@ __global__ __launch_bounds__(1024) void k_householder_signs(Mat<T> q, T *d) {
         const T dj = (s > (T)0) ? (T)-1 : (T)1;
         const T u = (T)1 + fabs(s);
         if (tid == 0) d[j] = dj;
+        const T inv = -dj / u;  // one division per step and thread (it was one per row: the kernel was bound by them)
         for (int i = j + 1 + ti; i < k; i += 32) {
-            const T li = -dj * W[i * ld + j] / u;
+            const T li = W[i * ld + j] * inv;
             for (int cc = j + 1 + tc; cc < k; cc += 32) W[i * ld + cc] -= li * W[j * ld + cc];
         }
         __syncthreads();
