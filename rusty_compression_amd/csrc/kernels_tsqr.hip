@@ -278,6 +278,72 @@ __device__ inline T safe_hypot(T a, T b) {  // ?lapy2
 template <typename T>
 __device__ inline T fast_sqrt_pos(T x) { return x > (T)0 ? x * fast_rsqrt(x) : (T)0; }
 
+// One Householder step of k_qrcp_small applied to the trailing columns (one LPP-lane group per column, NEJ rows per lane
+// from row j on) + the ?laqp2 norm down-date.  safe != 0: a read past the end of a column stays inside the LDS image (it
+// lands in the next column or in the norm / tau / permutation arrays behind the matrix), so the loads carry no bounds:
+// the reflector entries there are zero, the products are exact zeros and the sums are the same bits as with bounds.
+template <typename T, int NEJ, int LPP>
+__device__ __forceinline__ void qrcp_small_apply(T *A, int ld, int n, int j, int grp, int ll, int ngrp, const int *jp, T *vn1, T *vn2, T tj, int pivot, bool safe) {
+    const T *vcol = A + jp[j] * ld;
+    T v[NEJ];
+#pragma unroll
+    for (int e = 0; e < NEJ; ++e) {
+        int i = j + ll + LPP * e;
+        v[e] = (i < n) ? ((i == j) ? (T)1 : vcol[i]) : (T)0;
+    }
+    for (int p = j + 1 + grp; p < n; p += ngrp) {
+        T *xcol = A + jp[p] * ld;
+        T x[NEJ];
+        T dot = 0;
+        if (safe) {
+#pragma unroll
+            for (int e = 0; e < NEJ; ++e) {
+                x[e] = xcol[j + ll + LPP * e];
+                dot = fma(v[e], x[e], dot);
+            }
+        } else {
+#pragma unroll
+            for (int e = 0; e < NEJ; ++e) {
+                int i = j + ll + LPP * e;
+                x[e] = (i < n) ? xcol[i] : (T)0;
+                dot = fma(v[e], x[e], dot);
+            }
+        }
+        if (tj != (T)0) {
+            dot = group_sum_dpp<LPP>(dot);
+            const T f = tj * dot;
+#pragma unroll
+            for (int e = 0; e < NEJ; ++e) {
+                int i = j + ll + LPP * e;
+                if (i < n) { x[e] -= f * v[e]; xcol[i] = x[e]; }
+            }
+        }
+        if (pivot) {
+            const T xj = xcol[j];  // written by lane ll == 0 of this group: same wave, LDS ops are in order
+            const T vn = vn1[p];
+            if (vn != (T)0) {
+                T t = fabs(xj) * fast_rcp(vn);
+                T temp = (T)1 - t * t;
+                temp = temp > (T)0 ? temp : (T)0;
+                T rr = vn * fast_rcp(vn2[p]);
+                T temp2 = temp * rr * rr;
+                if (temp2 <= TNum<T>::tol3z()) {
+                    T ss = 0;
+#pragma unroll
+                    for (int e = 0; e < NEJ; ++e) {
+                        int i = j + ll + LPP * e;
+                        if (i > j && i < n) ss += x[e] * x[e];
+                    }
+                    ss = group_sum_dpp<LPP>(ss);
+                    if (ll == 0) { T nn = (j < n - 1) ? fast_sqrt_pos(ss) : (T)0; vn1[p] = nn; vn2[p] = nn; }
+                } else if (ll == 0) {
+                    vn1[p] = vn * fast_sqrt_pos(temp);
+                }
+            }
+        }
+    }
+}
+
 template <typename T, int NE, int NTHR>
 __global__ __launch_bounds__(NTHR) void k_qrcp_small(Mat<T> rin, int kmax, int pivot, int64_t *jpvt_out, Mat<T> rout, Mat<T> q2) {
     constexpr int LPP = 8;     // lanes per column in the update
@@ -293,6 +359,7 @@ __global__ __launch_bounds__(NTHR) void k_qrcp_small(Mat<T> rin, int kmax, int p
     int *jp = reinterpret_cast<int *>(tau + n);
     const int tid = threadIdx.x, lane = tid & 63;
     const int ll = tid % LPP, grp = tid / LPP;
+    const bool safe = LPP * NE <= 3 * n;  // rows read past a column's end stay inside the LDS image (see qrcp_small_apply)
 
     for (int e = tid; e < n * n; e += NTHR) {
         int i = e % n, cc = e / n;
@@ -303,7 +370,7 @@ __global__ __launch_bounds__(NTHR) void k_qrcp_small(Mat<T> rin, int kmax, int p
         T acc = 0;
         for (int i = ll; i < n; i += LPP) { T v = A[p * ld + i]; acc += v * v; }
         acc = group_sum_dpp<LPP>(acc);
-        if (ll == 0) { T nr = sqrt(acc); vn1[p] = nr; vn2[p] = nr; jp[p] = p; }
+        if (ll == 0) { T nr = sqrt(acc); vn1[p] = nr; vn2[p] = nr; jp[p] = p; tau[p] = (T)0; }  // tau: unbounded reads may land on it
     }
     __syncthreads();
 
@@ -342,58 +409,14 @@ __global__ __launch_bounds__(NTHR) void k_qrcp_small(Mat<T> rin, int kmax, int p
             }
         }
         __syncthreads();
-        {   // apply H_j to the remaining columns; one LPP-lane group per column
+        {   // apply H_j to the remaining columns; one LPP-lane group per column.  The register tile covers the rows that are
+            // left (the step is bound by the instructions issued, so short tiles for the late steps count)
+            const int rem = n - j;
             const T tj = tau[j];
-            const T *vcol = A + jp[j] * ld;
-            T v[NE];
-#pragma unroll
-            for (int e = 0; e < NE; ++e) {
-                int i = j + ll + LPP * e;
-                v[e] = (i < n) ? ((i == j) ? (T)1 : vcol[i]) : (T)0;
-            }
-            for (int p = j + 1 + grp; p < n; p += NGRP) {
-                T *xcol = A + jp[p] * ld;
-                T x[NE];
-                T dot = 0;
-#pragma unroll
-                for (int e = 0; e < NE; ++e) {
-                    int i = j + ll + LPP * e;
-                    x[e] = (i < n) ? xcol[i] : (T)0;
-                    dot = fma(v[e], x[e], dot);
-                }
-                if (tj != (T)0) {
-                    dot = group_sum_dpp<LPP>(dot);
-                    const T f = tj * dot;
-#pragma unroll
-                    for (int e = 0; e < NE; ++e) {
-                        int i = j + ll + LPP * e;
-                        if (i < n) { x[e] -= f * v[e]; xcol[i] = x[e]; }
-                    }
-                }
-                if (pivot) {
-                    const T xj = xcol[j];  // written by lane ll == 0 of this group: same wave, LDS ops are in order
-                    const T vn = vn1[p];
-                    if (vn != (T)0) {
-                        T t = fabs(xj) * fast_rcp(vn);
-                        T temp = (T)1 - t * t;
-                        temp = temp > (T)0 ? temp : (T)0;
-                        T rr = vn * fast_rcp(vn2[p]);
-                        T temp2 = temp * rr * rr;
-                        if (temp2 <= TNum<T>::tol3z()) {
-                            T ss = 0;
-#pragma unroll
-                            for (int e = 0; e < NE; ++e) {
-                                int i = j + ll + LPP * e;
-                                if (i > j && i < n) ss += x[e] * x[e];
-                            }
-                            ss = group_sum_dpp<LPP>(ss);
-                            if (ll == 0) { T nn = (j < n - 1) ? fast_sqrt_pos(ss) : (T)0; vn1[p] = nn; vn2[p] = nn; }
-                        } else if (ll == 0) {
-                            vn1[p] = vn * fast_sqrt_pos(temp);
-                        }
-                    }
-                }
-            }
+            if (NE > 12 && rem > 8 * 12) qrcp_small_apply<T, NE, LPP>(A, ld, n, j, grp, ll, NGRP, jp, vn1, vn2, tj, pivot, safe);
+            else if (NE > 8 && rem > 8 * 8) qrcp_small_apply<T, (NE > 12 ? 12 : NE), LPP>(A, ld, n, j, grp, ll, NGRP, jp, vn1, vn2, tj, pivot, safe);
+            else if (NE > 4 && rem > 8 * 4) qrcp_small_apply<T, (NE > 8 ? 8 : NE), LPP>(A, ld, n, j, grp, ll, NGRP, jp, vn1, vn2, tj, pivot, safe);
+            else qrcp_small_apply<T, (NE > 4 ? 4 : NE), LPP>(A, ld, n, j, grp, ll, NGRP, jp, vn1, vn2, tj, pivot, safe);
         }
         __syncthreads();
     }
