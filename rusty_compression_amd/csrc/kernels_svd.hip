@@ -55,7 +55,7 @@ __device__ inline void rr_pair(int N, int r, int pi, int &p, int &q) {
 // Always evaluated in f64: with f32 parameters c^2 + s^2 - 1 has a systematic sign, and the thousands of rotations a
 // column goes through inflate the singular values (3e-5 at n = 300).  A tiny angle (|d| >> |h|) is safe: t -> 0.
 template <typename T>
-__device__ inline void jacobi_rotation(T app, T aqq, T apq, T &c, T &s) {
+__device__ inline void jacobi_rotation(T app, T aqq, T apq, T &c, T &s, T *t_out = nullptr) {
     const double d = (double)aqq - (double)app, h = 2.0 * (double)apq;
     const double w = fma(d, d, h * h);
     double ri = __builtin_amdgcn_rsq(w);
@@ -67,6 +67,7 @@ __device__ inline void jacobi_rotation(T app, T aqq, T apq, T &c, T &s) {
     const double cd = fast_rsqrt(fma(t, t, 1.0));
     c = (T)cd;
     s = (T)(cd * t);
+    if (t_out) *t_out = (T)t;
 }
 
 // one rotation record of the log
@@ -127,9 +128,25 @@ __device__ inline unsigned tagged_get(const unsigned *p, unsigned e) {  // 0 = n
 #ifndef RC_JAC_ABL
 #define RC_JAC_ABL 0
 #endif
+// RC_JAC_TIMING: s_memtime stamps of wave 0 of the producer, summed per phase of the round (diagnostic builds only,
+// tools/jacobi_timing.py; a stamp costs a few hundred cycles and drains the wave's LDS queue)
+#ifdef RC_JAC_TIMING
+__device__ unsigned long long g_jac_dbg[8];
+#define RC_JTICK(k)                                                                      \
+    {                                                                                    \
+        unsigned long long now_;                                                         \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(now_)::"memory");  \
+        jt[k] += now_ - jlast;                                                           \
+        jlast = now_;                                                                    \
+    }
+#else
+#define RC_JTICK(k)
+#endif
 //   FULL   : n == LPP * NE and one group per pair slot: no row / column bounds, no slot loop (the round is bound by the
 //            number of instructions the 16 waves issue, and the predicates were a quarter of them)
-template <typename T, int LPP, int NE, bool FULL>
+//   CN     : squared column norms are carried in LDS and updated by the rotation (app -= t apq, aqq += t apq) instead of
+//            being recomputed by every pair in every round; refreshed from the columns at the start of each sweep
+template <typename T, int LPP, int NE, bool FULL, bool CN>
 __global__ __launch_bounds__(LPP == 16 ? 1024 : 512) void k_jacobi_lds(Mat<T> g, Rot<T> *log, int *sweeps_out, Mat<T> uc, T *s, int *order_out, int max_sweeps,
                                                                        int fused, unsigned *vsync, unsigned long long *chk, unsigned *epoch_p, Mat<T> vc, int *health, int ld) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
@@ -224,15 +241,29 @@ __global__ __launch_bounds__(LPP == 16 ? 1024 : 512) void k_jacobi_lds(Mat<T> g,
     }
     __syncthreads();
 
+#ifdef RC_JAC_TIMING
+    unsigned long long jt[6] = {0, 0, 0, 0, 0, 0}, jlast;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(jlast)::"memory");
+#endif
     int sweep = 0;
     for (; sweep < max_sweeps; ++sweep) {
         if (tid == 0) sh_rot = 0;
+        if (CN) {
+            for (int j = grp; j < n; j += ngrp) {
+                const T *gj = G + j * ld;
+                T acc = 0;
+                for (int i = ll; i < n; i += LPP) acc = fma(gj[i], gj[i], acc);
+                acc = group_sum_dpp<LPP>(acc);
+                if (ll == 0) sig[j] = acc;
+            }
+        }
         __syncthreads();
         // circle-method pair of this group, advanced round by round when the group owns one pair slot (no integer
         // modulo on the per-round critical path): slot 0 pairs N - 1 with r, slot pi pairs (r + pi) with (r - pi) mod N - 1
         const bool one_slot = FULL || npairs <= ngrp;
         int pr = grp % (N - 1), qr = ((N - 1) - grp % (N - 1)) % (N - 1);
         for (int r = 0; r < N - 1; ++r) {
+            RC_JTICK(5)  // barrier + loop control
             for (int pi = grp; pi < npairs; pi += FULL ? (1 << 20) : ngrp) {  // FULL: exactly one trip
                 int p, q;
                 if (one_slot) {
@@ -257,13 +288,22 @@ __global__ __launch_bounds__(LPP == 16 ? 1024 : 512) void k_jacobi_lds(Mat<T> g,
                         a[e] = (FULL || i < n) ? gp[i] : (T)0;
                         b[e] = (FULL || i < n) ? gq[i] : (T)0;
                         }
-                        app = fma(a[e], a[e], app); aqq = fma(b[e], b[e], aqq); apq = fma(a[e], b[e], apq);
+                        if (!CN) { app = fma(a[e], a[e], app); aqq = fma(b[e], b[e], aqq); }
+                        apq = fma(a[e], b[e], apq);
                     }
-                    if (!(RC_JAC_ABL & 8)) { app = group_sum_dpp<LPP>(app); aqq = group_sum_dpp<LPP>(aqq); apq = group_sum_dpp<LPP>(apq); }
+                    RC_JTICK(0)  // LDS reads + dot products
+                    if (CN) { app = sig[p]; aqq = sig[q]; apq = group_sum_dpp<LPP>(apq); }
+                    else if (!(RC_JAC_ABL & 8)) { app = group_sum_dpp<LPP>(app); aqq = group_sum_dpp<LPP>(aqq); apq = group_sum_dpp<LPP>(apq); }
+                    RC_JTICK(1)  // group reduction
                     // rotate iff |apq| > tol * sqrt(app * aqq)   (uniform over the LPP lanes)
                     if ((RC_JAC_ABL & 32) || apq * apq > tol2 * app * aqq) {
                         if (RC_JAC_ABL & 2) { rot.c = (T)0.8 + apq * (T)1e-30; rot.s = (T)0.6 + app * (T)1e-30; }
-                        else jacobi_rotation(app, aqq, apq, rot.c, rot.s);
+                        else if (CN) {
+                            T t;
+                            jacobi_rotation(app, aqq, apq, rot.c, rot.s, &t);
+                            if (ll == 0) { sig[p] = app - t * apq; sig[q] = aqq + t * apq; }
+                        } else jacobi_rotation(app, aqq, apq, rot.c, rot.s);
+                        RC_JTICK(2)  // rotation parameters
 #pragma unroll
                         for (int e = 0; e < NE; ++e) {
                             int i = ll + LPP * e;
@@ -279,17 +319,25 @@ __global__ __launch_bounds__(LPP == 16 ? 1024 : 512) void k_jacobi_lds(Mat<T> g,
                         if (ll == 0 && apq * apq > tol * (T)0.0625 * app * aqq) sh_rot = 2;  // plain store: every writer writes 2
                     }
                 }
+                RC_JTICK(3)  // rotation applied, written back (LDS queue drained by the stamp)
                 if (ll == 0 && !(RC_JAC_ABL & 1)) {
                     if (fused) rot_publish(log + ((size_t)sweep * (N - 1) + r) * npairs + pi, chk + ((size_t)sweep * (N - 1) + r) * npairs + pi, rot, key);
                     else log[((size_t)sweep * (N - 1) + r) * npairs + pi] = rot;
                 }
             }
+            RC_JTICK(4)  // record published
             lds_barrier();  // pairs of one round are disjoint; the next round re-pairs the columns
         }
         const int rotated = sh_rot;
         __syncthreads();
         if (!(RC_JAC_ABL & 32) && rotated < 2) { ++sweep; break; }
     }
+#ifdef RC_JAC_TIMING
+    if (tid == 0) {
+        for (int k2 = 0; k2 < 6; ++k2) g_jac_dbg[k2] = jt[k2];
+        g_jac_dbg[6] = (unsigned long long)sweep * (N - 1);
+    }
+#endif
     if (tid == 0) {
         *sweeps_out = sweep;
         if (fused) tagged_put(vsync, epoch, (unsigned)sweep);
@@ -528,14 +576,14 @@ static void jacobi_global(rc_context *c, Mat<T> g, Mat<T> v, Mat<T> uc, T *s, Ma
     hipLaunchKernelGGL(k_jacobi_emit<T>, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, c->stream, g, v, sig, order, uc, vc);
 }
 
-template <typename T, int LPP, int NE, bool FULL>
+template <typename T, int LPP, int NE, bool FULL, bool CN>
 static void launch_lds_impl(rc_context *c, Mat<T> g, Mat<T> uc, T *s, Mat<T> vc, size_t lds, int ld, int max_sweeps) {
     const int n = (int)g.rows, N = (n + 1) & ~1;
     ArenaMark mark(c);
     Rot<T> *log = c->alloc<Rot<T>>((size_t)max_sweeps * (N - 1) * (N / 2));
     int *sweeps = c->alloc<int>(1);
     int *order = c->alloc<int>((size_t)n);
-    auto kern = k_jacobi_lds<T, LPP, NE, FULL>;
+    auto kern = k_jacobi_lds<T, LPP, NE, FULL, CN>;
     static bool attr_set[64] = {};
     if (!attr_set[c->device & 63]) {
         RC_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 2048));
@@ -580,8 +628,11 @@ static void launch_lds(rc_context *c, Mat<T> g, Mat<T> uc, T *s, Mat<T> vc, size
     // the bound-free instance: every lane row and every pair slot is real (n = 32, 64, 128 with 16 lanes per pair)
     static const int full_env = [] { const char *e = getenv("RC_JACOBI_FULL"); return e ? atoi(e) : 1; }();
     const int n = (int)g.rows;
-    if (full_env && (LPP == 16 || LPP == 8) && n == LPP * NE && (n / 2) * LPP <= (LPP == 16 ? 1024 : 512)) launch_lds_impl<T, LPP, NE, true>(c, g, uc, s, vc, lds, ld, max_sweeps);
-    else launch_lds_impl<T, LPP, NE, false>(c, g, uc, s, vc, lds, ld, max_sweeps);
+    static const int cn_env = [] { const char *e = getenv("RC_JACOBI_CACHED_NORMS"); return e ? atoi(e) : 0; }();
+    const bool full = full_env && (LPP == 16 || LPP == 8) && n == LPP * NE && (n / 2) * LPP <= (LPP == 16 ? 1024 : 512);
+    if (full && cn_env && LPP == 16) launch_lds_impl<T, LPP, NE, true, true>(c, g, uc, s, vc, lds, ld, max_sweeps);
+    else if (full) launch_lds_impl<T, LPP, NE, true, false>(c, g, uc, s, vc, lds, ld, max_sweeps);
+    else launch_lds_impl<T, LPP, NE, false, false>(c, g, uc, s, vc, lds, ld, max_sweeps);
 }
 
 template <typename T, int LPP>
@@ -626,3 +677,7 @@ template void jacobi_svd<double>(rc_context *, Mat<double>, Mat<double>, Mat<dou
 template void jacobi_svd<float>(rc_context *, Mat<float>, Mat<float>, Mat<float>, float *, Mat<float>);
 
 }  // namespace rc
+
+#ifdef RC_JAC_TIMING
+extern "C" void rc_debug_jacobi_timing(unsigned long long *out) { (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(rc::g_jac_dbg), 8 * sizeof(unsigned long long)); }
+#endif
