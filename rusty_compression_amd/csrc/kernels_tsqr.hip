@@ -110,17 +110,40 @@ __global__ __launch_bounds__(1024) void k_chol_inv(Mat<T> g, Mat<T> r_out, Mat<T
         }
     }
 
+    // One loop for the factor and its inverse.  X = R^-1 by the right-looking column recurrence of X R = I:
+    //   X(:, j) /= r_jj ;  X(:, c) -= X(:, j) R(j, c)  for c > j
+    // needs exactly the row of R that step j of the factorization completes, so both rank-1 updates share the step's one
+    // barrier (the separate bottom-up Gauss-Jordan pass was another n dependent steps).  X is register-tiled like the
+    // factor; only tiles on or above the block diagonal exist (a <= b).
+    T xr[NT][NT];
+#pragma unroll
+    for (int a = 0; a < NT; ++a)
+#pragma unroll
+        for (int b = 0; b < NT; ++b) xr[a][b] = (ti + 32 * a == tc + 32 * b) ? (T)1 : (T)0;
+    T *colbuf = A;  // 2 * n
     for (int j = 0; j < n; ++j) {
         T *rb = rowbuf + (j & 1) * n;
+        T *cb = colbuf + (j & 1) * n;
         const int ja = j >> 5, jt = j & 31;
         if (ti == jt) {  // owners of row j publish it (unscaled; rb[j] is the pivot)
 #pragma unroll
             for (int a = 0; a < NT; ++a)
                 if (a == ja) {
 #pragma unroll
-                    for (int b = 0; b < NT; ++b) {
+                    for (int b = a; b < NT; ++b) {
                         const int c = tc + 32 * b;
                         if (c >= j && c < n) rb[c] = reg[a][b];
+                    }
+                }
+        }
+        if (tc == jt) {  // owners of column j of X publish it (before its scaling; rows <= j)
+#pragma unroll
+            for (int b = 0; b < NT; ++b)
+                if (b == ja) {
+#pragma unroll
+                    for (int a = 0; a <= b; ++a) {
+                        const int i = ti + 32 * a;
+                        if (i <= j) cb[i] = xr[a][b];
                     }
                 }
         }
@@ -139,71 +162,35 @@ __global__ __launch_bounds__(1024) void k_chol_inv(Mat<T> g, Mat<T> r_out, Mat<T
             const int i = ti + 32 * a;
             if (i == j) {  // row j becomes the final row of R
 #pragma unroll
-                for (int b = 0; b < NT; ++b) {
+                for (int b = a; b < NT; ++b) {
                     const int c = tc + 32 * b;
                     if (c >= j && c < n) reg[a][b] *= invr;
                 }
             } else if (i > j && i < n) {
                 const T w = rb[i] * invd;
 #pragma unroll
-                for (int b = 0; b < NT; ++b) reg[a][b] -= w * cv[b];  // entries below the diagonal are never used
+                for (int b = a; b < NT; ++b) reg[a][b] -= w * cv[b];  // entries below the diagonal are never used
+            }
+            if (i <= j) {  // X(i, c) -= X(i, j) R(j, c) = (cb[i] / r_jj) (rb[c] / r_jj)
+                const T xj = cb[i];
+                const T w = xj * invd;
+#pragma unroll
+                for (int b = a; b < NT; ++b) {
+                    xr[a][b] -= w * cv[b];
+                    if (b == ja && tc == jt) xr[a][b] = xj * invr;  // column j itself: final
+                }
             }
         }
     }
-    // R -> global and -> LDS (column j of R is broadcast from there during the inversion)
 #pragma unroll
     for (int a = 0; a < NT; ++a)
 #pragma unroll
         for (int b = 0; b < NT; ++b) {
             const int i = ti + 32 * a, c = tc + 32 * b;
             if (i < n && c < n) {
-                const T v = (c >= i) ? reg[a][b] : (T)0;
-                r_out.at(i, c) = v;
-                A[i * ld + c] = v;
+                r_out.at(i, c) = (b >= a && c >= i) ? reg[a][b] : (T)0;
+                rinv_out.at(i, c) = (b >= a && c >= i) ? xr[a][b] : (T)0;
             }
-        }
-    // X = R^{-1} by Gauss-Jordan from the bottom row up, X register-tiled like the factor:
-    //   row j of X /= r_jj ; for i < j: row i -= R[i, j] * row j      (one barrier per step)
-#pragma unroll
-    for (int a = 0; a < NT; ++a)
-#pragma unroll
-        for (int b = 0; b < NT; ++b) reg[a][b] = (ti + 32 * a == tc + 32 * b) ? (T)1 : (T)0;
-    __syncthreads();
-    for (int j = n - 1; j >= 0; --j) {
-        T *rb = rowbuf + (j & 1) * n;
-        const int ja = j >> 5, jt = j & 31;
-        const T xs = fast_rcp(A[j * ld + j]);
-        if (ti == jt) {  // owners of row j scale it and publish it
-#pragma unroll
-            for (int a = 0; a < NT; ++a)
-                if (a == ja) {
-#pragma unroll
-                    for (int b = 0; b < NT; ++b) {
-                        const int c = tc + 32 * b;
-                        if (c >= j && c < n) { reg[a][b] *= xs; rb[c] = reg[a][b]; }
-                    }
-                }
-        }
-        __syncthreads();
-        T cv[NT];
-#pragma unroll
-        for (int b = 0; b < NT; ++b) { const int c = tc + 32 * b; cv[b] = (c >= j && c < n) ? rb[c] : (T)0; }
-#pragma unroll
-        for (int a = 0; a < NT; ++a) {
-            const int i = ti + 32 * a;
-            if (i < j) {
-                const T w = A[i * ld + j];
-#pragma unroll
-                for (int b = 0; b < NT; ++b) reg[a][b] -= w * cv[b];
-            }
-        }
-    }
-#pragma unroll
-    for (int a = 0; a < NT; ++a)
-#pragma unroll
-        for (int b = 0; b < NT; ++b) {
-            const int i = ti + 32 * a, c = tc + 32 * b;
-            if (i < n && c < n) rinv_out.at(i, c) = (c >= i) ? reg[a][b] : (T)0;
         }
 }
 
