@@ -28,8 +28,9 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 # hardware queues for the in-flight compressions (the HIP default of 4 serialises the streams); must be set before
-# the HIP runtime initialises.  Measured (tools/stream_sweep.sh): 24 queues x 40 streams is the best point (917-922
-# compressions/s), 8 queues 600, 16 queues 800, 32 queues 845-910, 48 queues with >= 48 streams collapses to 316.
+# the HIP runtime initialises.  Measured (tools/stream_sweep.sh): 24 queues x 42 streams is the best point (975-980
+# compressions/s; 40 streams 951-960, 44-46 streams 961, 48 streams 908), 16 or 20 queues 885-900, 28-32 queues
+# 845-890, 48 queues with >= 48 streams collapses to 316.
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "24")
 
 F64_MFMA_PEAK_TFLOPS = 78.6   # MI355X f64 matrix peak (vendor datasheet value)
@@ -60,8 +61,8 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=256)
-    ap.add_argument("--warmup", type=int, default=32)
-    ap.add_argument("--streams", type=int, default=40, help="independent compressions in flight per GPU")
+    ap.add_argument("--warmup", type=int, default=42)
+    ap.add_argument("--streams", type=int, default=42, help="independent compressions in flight per GPU")
     ap.add_argument("--size", type=int, default=8192)
     ap.add_argument("--rank", type=int, default=128)
     ap.add_argument("--oversample", type=int, default=5)
@@ -69,6 +70,8 @@ def main():
     ap.add_argument("--no-id", action="store_true", help="rSVD only (skip QR-from-range + column ID)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-baseline-reps", type=int, default=1)
+    ap.add_argument("--lane-events", action="store_true",
+                    help="diagnostic: HIP events around every timed step on its lane's stream; start/end offsets go to stderr")
     ap.add_argument("--profile-concurrent", action="store_true",
                     help="diagnostic: per-stage HIP-event timers with ALL streams busy (eager launches), printed to stderr")
     args = ap.parse_args()
@@ -145,19 +148,45 @@ def main():
                 ctx.check(_lib.lib().rc_graph_begin_capture(ctx._h))
                 call()
                 ctx.check(_lib.lib().rc_graph_end_capture(ctx._h, ctypes.byref(graph)))
+                # first launch of the executable graph (uploads it to the device) belongs to the lane's set-up, so that a
+                # small --warmup does not leave first launches inside the timed region
+                ctx.check(_lib.lib().rc_graph_launch(ctx._h, graph))
+                ctx.synchronize()
             lanes.append(dict(stream=st, ctx=ctx, a=a, bufs=bufs, out=out, call=call, graph=graph))
 
-    def step(i):
+    lane_events = []
+
+    def step(i, timed=False):
         ln = lanes[i % S]
+        if timed and args.lane_events:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(ln["stream"])
         if ln["graph"]:
             ln["ctx"].check(_lib.lib().rc_graph_launch(ln["ctx"]._h, ln["graph"]))
         else:
             ln["call"]()
+        if timed and args.lane_events:
+            e1.record(ln["stream"])
+            lane_events.append((i, e0, e1))
 
     def sync_all():
+        # An event per lane behind its last command, then the waits.  Measured on this stack (tools/steps_sweep.sh,
+        # --lane-events): with more than ~28 streams holding work, a wait that starts while the other streams carry no
+        # event (hipStreamSynchronize per stream, also event-record + event-wait stream by stream, also with
+        # HSA_ENABLE_INTERRUPT=0 or a hipStreamQuery behind every launch) returns after max(259 ms, work): 42 compressions
+        # are done after 47 ms by their event timestamps, the wait comes back after 259 ms.  With an event recorded on
+        # EVERY stream before the first wait the waits return on time.  RC_BENCH_SYNC=ctx reproduces the old behaviour.
+        evs = []
+        for ln in ([] if os.environ.get("RC_BENCH_SYNC") == "ctx" else lanes):
+            ev = torch.cuda.Event()
+            ev.record(ln["stream"])
+            evs.append(ev)
+        for ev in evs:
+            ev.synchronize()
+        if os.environ.get("RC_BENCH_SYNC") != "ctx":
+            torch.cuda.synchronize()
         for ln in lanes:
             ln["ctx"].synchronize()
-        torch.cuda.synchronize()
 
     # ---- sanity of what is being timed (lane 0) -----------------------------------------
     sync_all()
@@ -204,10 +233,14 @@ def main():
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for i in range(args.steps):
-        step(i)
+        step(i, True)
     t_issue = time.perf_counter()
     sync_all()
     t1 = time.perf_counter()
+    if lane_events and rank == 0:
+        ref = lane_events[0][1]
+        for i, e0, e1 in lane_events:
+            print(f"step {i:4d} lane {i % S:3d} start {ref.elapsed_time(e0):9.3f} ms end {ref.elapsed_time(e1):9.3f} ms", file=sys.stderr)
     if dist is not None:
         dist.barrier()
     # every captured tall-skinny fast path must have certified itself (no fallback exists inside a graph)

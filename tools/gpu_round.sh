@@ -18,7 +18,7 @@ python -c "
 import json; d=json.load(open('gpurun_out/bench_default.json')); print('default:', d['value'], 'c/s', d['ms_per_step'], 'ms/step', 'host issue', d['host_issue_ms_per_step'], 'roofline', d['roofline']['achieved'], d['roofline']['frac'], 'cpu', d['cpu_baseline'])"
 echo "== rocprofv3 kernel trace of the bench command" | tee -a gpurun_out/progress.log
 rm -rf gpurun_out/prof_bench
-cd /tmp && timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_bench -- python3 $R/bench.py --steps 80 --warmup 40 --no-cpu-baseline > $R/gpurun_out/rocprof_bench.log 2>&1
+cd /tmp && timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_bench -- python3 $R/bench.py --steps 84 --warmup 42 --no-cpu-baseline > $R/gpurun_out/rocprof_bench.log 2>&1
 echo "rocprof exit=$?" | tee -a $R/gpurun_out/progress.log
 cd $R && python - <<'PY'
 import csv,glob,os
