@@ -60,7 +60,7 @@ def work_model(m, n, k, p, with_id=True):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=256)
+    ap.add_argument("--steps", type=int, default=512)
     ap.add_argument("--warmup", type=int, default=42)
     ap.add_argument("--streams", type=int, default=42, help="independent compressions in flight per GPU")
     ap.add_argument("--size", type=int, default=8192)
