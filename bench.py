@@ -69,7 +69,7 @@ def main():
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying hipGraphs")
     ap.add_argument("--no-id", action="store_true", help="rSVD only (skip QR-from-range + column ID)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-baseline-reps", type=int, default=1)
+    ap.add_argument("--cpu-baseline-reps", type=int, default=2, help="compressions timed on the host (about 5 s each on the GPU box)")
     ap.add_argument("--lane-events", action="store_true",
                     help="diagnostic: HIP events around every timed step on its lane's stream; start/end offsets go to stderr")
     ap.add_argument("--profile-concurrent", action="store_true",
