@@ -31,6 +31,7 @@
 // every workgroup leaves, the certificate flag is raised and the caller falls back to the
 // multi-kernel path (or, inside a hipGraph, reports through the health word).
 #include "rc_common.hpp"
+#include <cstdlib>
 #include "rc_device.hpp"
 
 #include <mutex>
@@ -471,7 +472,8 @@ void geqp3_wide_coop(rc_context *c, Mat<T> w, Mat<T> wf, int64_t kmax, int64_t *
     a.sync = c->alloc<unsigned>(4);
     a.sem = coop_semaphore(c->device);
     a.flag = flag;
-    hipLaunchKernelGGL(k_coop_gate, dim3(1), dim3(256), 0, c->stream, a.sem, (unsigned)g, (unsigned)kCoopBudgetCUs, a.sync, a.hdr, 2 * g * 5);
+    static const int budget = [] { const char *e = getenv("RC_COOP_BUDGET"); const int v = e ? atoi(e) : 0; return v >= 32 && v <= 256 ? v : kCoopBudgetCUs; }();  // experiments
+    hipLaunchKernelGGL(k_coop_gate, dim3(1), dim3(256), 0, c->stream, a.sem, (unsigned)g, (unsigned)budget, a.sync, a.hdr, 2 * g * 5);
 #define RC_COOP(NE_, CPG_) hipLaunchKernelGGL((k_wq_coop<T, NE_, CPG_>), dim3((unsigned)g), dim3(512), 0, c->stream, a)
     if (ne == 8) RC_COOP(8, 8);
     else if (ne == 16) RC_COOP(16, 4);
