@@ -153,6 +153,20 @@ def test_pivoted_qr_shapes_against_live_oracle(dtype, shape):
     assert np.abs(gq.T @ gq - np.eye(gq.shape[1])).max() <= (1e-13 if dtype == np.float64 else 1e-5)
 
 
+@pytest.mark.parametrize("n", [8, 33, 64, 65, 100, 133, 160, 161, 224])
+def test_tall_pivoted_qr_across_the_register_tile_variants(n):
+    """4096 x n Gaussian, f64: the tall-skinny path (CholeskyQR2 + small QRCP + sign fix) switches register tilings at
+    n = 64 / 144 / 160 (k_chol_inv, k_qrcp_small) and leaves the fast path above its limits; pivots identical to
+    ?geqp3, Q, R with LAPACK's signs to 1e-12, Q orthonormal to 1e-13 at every size."""
+    rng = np.random.default_rng(1000 + n)
+    a = rng.standard_normal((4096, n))
+    q, r, ind = o.pivoted_qr(a)
+    gq, gr, gi = (npy(t) for t in rc.pivoted_qr(a))
+    assert np.array_equal(gi, ind)
+    assert rel(gr, r) <= 1e-12 and rel(gq, q) <= 1e-12
+    assert np.abs(gq.T @ gq - np.eye(n)).max() <= 1e-13
+
+
 def test_pivoted_qr_accepts_any_layout_and_leaves_input_untouched():
     rng = np.random.default_rng(9)
     a = o.random_approximate_low_rank_matrix((120, 80), 1.0, 1e-5, rng)
