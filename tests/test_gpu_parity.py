@@ -842,6 +842,38 @@ def test_cpp_mirror_runs_the_reference_examples(tmp_path):
     assert "ALL OK" in res.stdout
 
 
+_JACOBI_VARIANT_SNIPPET = r"""
+import numpy as np, torch, sys
+import rusty_compression_amd as rc
+rng = np.random.default_rng(5)
+worst = 0.0
+for n in (32, 64, 100, 128):
+    a = rng.standard_normal((n, n)) @ np.diag(np.geomspace(1.0, 1e-9, n)) @ rng.standard_normal((n, n))
+    u, s, vt = (t.cpu().numpy() for t in rc.compute_svd(torch.from_numpy(a).cuda()))
+    sref = np.linalg.svd(a, compute_uv=False)
+    worst = max(worst, np.abs(s - sref).max() / sref[0], np.abs((u * s) @ vt - a).max() / sref[0],
+                np.abs(u.T @ u - np.eye(n)).max(), np.abs(vt @ vt.T - np.eye(n)).max())
+print("WORST", worst)
+sys.exit(0 if worst < 1e-12 else 1)
+"""
+
+
+@pytest.mark.parametrize("env", [{"RC_JACOBI_FULL": "0"}, {"RC_JACOBI_LPP": "8"}, {"RC_JACOBI_CACHED_NORMS": "1"}, {"RC_JACOBI_FUSED_V": "0"},
+                                 {"RC_JACOBI_PITCH": "0"}])
+def test_jacobi_kernel_variants_behind_the_environment_switches(env):
+    """The LDS Jacobi kernel has opt-in / fallback instances chosen by process-wide environment switches (bounded
+    instance, 8 lanes per pair, column norms carried in LDS, separate replay of the right vectors, odd column pitch);
+    each runs in its own process: singular values, U S V^T, and the orthogonality of U and V to 1e-12 against numpy."""
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    res = subprocess.run([sys.executable, "-c", _JACOBI_VARIANT_SNIPPET], capture_output=True, text=True, timeout=300, cwd=root,
+                         env=dict(os.environ, PYTHONPATH=root, **env))
+    assert res.returncode == 0, res.stdout + res.stderr
+
+
 def test_graph_replay_matches_eager_and_survives_workspace_growth():
     """hipGraph capture of the fused pipeline (rc_graph_*): the replay reproduces the eager result bit
     for bit, and an eager call that outgrows the workspace afterwards must not invalidate the graph
