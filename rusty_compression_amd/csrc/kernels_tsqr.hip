@@ -331,6 +331,24 @@ __device__ __forceinline__ void qrcp_small_apply(T *A, int ld, int n, int j, int
     }
 }
 
+// x <- H_j x for the Q2 formation of k_qrcp_small: rows ll + LPP e, register blocks E0 .. NE - 1 (the blocks below E0 lie
+// above row j, where the reflector is zero).
+template <typename T, int NE, int LPP, int E0>
+__device__ __forceinline__ void qrcp_small_reflect(T (&x)[NE], const T *vcol, T tj, int j, int n, int ll) {
+    T v[NE];
+    T dot = 0;
+#pragma unroll
+    for (int e = E0; e < NE; ++e) {
+        int i = ll + LPP * e;
+        v[e] = 0;
+        if (i < n && i >= j) { v[e] = (i == j) ? (T)1 : vcol[i]; dot = fma(v[e], x[e], dot); }
+    }
+    dot = group_sum_dpp<LPP>(dot);
+    const T f = tj * dot;
+#pragma unroll
+    for (int e = E0; e < NE; ++e) x[e] -= f * v[e];
+}
+
 template <typename T, int NE, int NTHR>
 __global__ __launch_bounds__(NTHR) void k_qrcp_small(Mat<T> rin, int kmax, int pivot, int64_t *jpvt_out, Mat<T> rout, Mat<T> q2) {
     constexpr int LPP = 8;     // lanes per column in the update
@@ -425,18 +443,13 @@ __global__ __launch_bounds__(NTHR) void k_qrcp_small(Mat<T> rin, int kmax, int p
                 const T tj = tau[j];
                 if (tj == (T)0) continue;
                 const T *vcol = A + jp[j] * ld;
-                T v[NE];
-                T dot = 0;
-#pragma unroll
-                for (int e = 0; e < NE; ++e) {
-                    int i = ll + LPP * e;
-                    v[e] = 0;
-                    if (i < n && i >= j) { v[e] = (i == j) ? (T)1 : vcol[i]; dot = fma(v[e], x[e], dot); }
-                }
-                dot = group_sum_dpp<LPP>(dot);
-                const T f = tj * dot;
-#pragma unroll
-                for (int e = 0; e < NE; ++e) x[e] -= f * v[e];
+                // register blocks that lie entirely above row j hold only zeros of the reflector: the instance that starts at
+                // the largest multiple of four blocks below row j skips them (same sums, the skipped products are exact zeros)
+                const int e0 = j / LPP;
+                if (NE > 12 && e0 >= 12) qrcp_small_reflect<T, NE, LPP, (NE > 12 ? 12 : 0)>(x, vcol, tj, j, n, ll);
+                else if (NE > 8 && e0 >= 8) qrcp_small_reflect<T, NE, LPP, (NE > 8 ? 8 : 0)>(x, vcol, tj, j, n, ll);
+                else if (NE > 4 && e0 >= 4) qrcp_small_reflect<T, NE, LPP, (NE > 4 ? 4 : 0)>(x, vcol, tj, j, n, ll);
+                else qrcp_small_reflect<T, NE, LPP, 0>(x, vcol, tj, j, n, ll);
             }
 #pragma unroll
             for (int e = 0; e < NE; ++e) {
