@@ -12,9 +12,12 @@ Workload (BASELINE.json configs[2], the one `metric` is quoted on; it fits one G
 
 Independent matrices are the unit of parallelism: every rank
 compresses its own matrices (weak scaling, no data-path collective); within a rank
-`--streams S` independent compressions are in flight on S HIP streams, each replayed
-from a hipGraph, so the launch-bound pivot chain of one overlaps the GEMMs of another.
-Rank 0 prints ONE JSON line.
+`--streams S` independent compressions are in flight on S HIP streams ("lanes"), each
+replayed from a hipGraph, so the launch-bound pivot chain of one overlaps the GEMMs of
+another.  ONE STEP = one compression on EACH of the S lanes (config.compressions_per_step = S):
+`--steps K --warmup W` runs W untimed and K timed rounds over all lanes, so every command
+line measures the steady state (K*S compressions per GPU), `value` = K*S*N / elapsed and
+`ms_per_step` = elapsed / K.  Rank 0 prints ONE JSON line.
 """
 import argparse
 import ctypes
@@ -60,8 +63,8 @@ def work_model(m, n, k, p, with_id=True):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=512)
-    ap.add_argument("--warmup", type=int, default=42)
+    ap.add_argument("--steps", type=int, default=12, help="timed rounds; one round = one compression on each lane")
+    ap.add_argument("--warmup", type=int, default=2, help="untimed rounds")
     ap.add_argument("--streams", type=int, default=42, help="independent compressions in flight per GPU")
     ap.add_argument("--size", type=int, default=8192)
     ap.add_argument("--rank", type=int, default=128)
@@ -70,6 +73,7 @@ def main():
     ap.add_argument("--no-id", action="store_true", help="rSVD only (skip QR-from-range + column ID)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-baseline-reps", type=int, default=2, help="compressions timed on the host (about 5 s each on the GPU box)")
+    ap.add_argument("--no-h2d", action="store_true", help="skip the second throughput figure that re-uploads A before every compression")
     ap.add_argument("--lane-events", action="store_true",
                     help="diagnostic: HIP events around every timed step on its lane's stream; start/end offsets go to stderr")
     ap.add_argument("--profile-concurrent", action="store_true",
@@ -169,24 +173,19 @@ def main():
             e1.record(ln["stream"])
             lane_events.append((i, e0, e1))
 
+    ctx_arr = (ctypes.c_void_p * S)(*[ln["ctx"]._h.value for ln in lanes])
+
     def sync_all():
-        # An event per lane behind its last command, then the waits.  Measured on this stack (tools/steps_sweep.sh,
-        # --lane-events): with more than ~28 streams holding work, a wait that starts while the other streams carry no
-        # event (hipStreamSynchronize per stream, also event-record + event-wait stream by stream, also with
-        # HSA_ENABLE_INTERRUPT=0 or a hipStreamQuery behind every launch) returns after max(259 ms, work): 42 compressions
-        # are done after 47 ms by their event timestamps, the wait comes back after 259 ms.  With an event recorded on
-        # EVERY stream before the first wait the waits return on time.  RC_BENCH_SYNC=ctx reproduces the old behaviour.
-        evs = []
-        for ln in ([] if os.environ.get("RC_BENCH_SYNC") == "ctx" else lanes):
-            ev = torch.cuda.Event()
-            ev.record(ln["stream"])
-            evs.append(ev)
-        for ev in evs:
-            ev.synchronize()
-        if os.environ.get("RC_BENCH_SYNC") != "ctx":
-            torch.cuda.synchronize()
-        for ln in lanes:
-            ln["ctx"].synchronize()
+        # rc_synchronize_all: a completion event on EVERY lane's stream first, the waits afterwards.  Measured on this
+        # stack (tools/steps_sweep.sh, --lane-events): with more than ~28 streams holding work, stream-by-stream waits
+        # return after max(259 ms, work); with an event recorded on every stream before the first wait they return on
+        # time.  RC_BENCH_SYNC=ctx reproduces the old behaviour (rc_synchronize context by context).
+        if os.environ.get("RC_BENCH_SYNC") == "ctx":
+            for ln in lanes:
+                ln["ctx"].synchronize()
+            return
+        st = _lib.lib().rc_synchronize_all(ctx_arr, ctypes.c_int32(S))
+        assert st == 0, "rc_synchronize_all failed with status %d" % st
 
     # ---- sanity of what is being timed (lane 0) -----------------------------------------
     sync_all()
@@ -220,22 +219,25 @@ def main():
         lib.rc_profile_enable(ln["ctx"]._h, 0)
         return out
 
-    # ---- warm-up, then K timed steps -----------------------------------------------------
-    for i in range(args.warmup):
-        step(i)
+    # ---- warm-up, then K timed steps (a step = one compression on each of the S lanes) ----
+    for _ in range(args.warmup):
+        for i in range(S):
+            step(i)
     sync_all()
     prof_before = profile_samples(lanes[0], _lib.lib(), 4)
-    for i in range(min(args.warmup, S)):
+    for i in range(S):   # every lane busy again after the single-lane profiling samples
         step(i)
     sync_all()
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for i in range(args.steps):
-        step(i, True)
+    for _ in range(args.steps):
+        for i in range(S):
+            step(i, True)
     t_issue = time.perf_counter()
     sync_all()
+    torch.cuda.synchronize()
     t1 = time.perf_counter()
     if lane_events and rank == 0:
         ref = lane_events[0][1]
@@ -251,6 +253,25 @@ def main():
         t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if rehearsal else "cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+
+    # ---- second figure: every compression first re-uploads its A from pinned host memory on its own
+    # lane (the reference's API takes host ndarrays); one round over all lanes, never `value` ------------------------
+    h2d = None
+    if rank == 0 and world == 1 and not args.no_h2d:
+        a_pinned = torch.empty((m, n), dtype=dt, pin_memory=True)
+        a_pinned.copy_(lanes[0]["a"])
+        sync_all()
+        th0 = time.perf_counter()
+        for i in range(S):
+            with torch.cuda.stream(lanes[i]["stream"]):
+                lanes[i]["a"].copy_(a_pinned, non_blocking=True)
+            step(i)
+        sync_all()
+        torch.cuda.synchronize()
+        th = time.perf_counter() - th0
+        h2d = {"value_including_h2d": round(S / th, 3), "unit": "compressions/s", "compressions": S,
+               "h2d_gb_per_s": round(S * 8.0 * m * n / th / 1e9, 2),
+               "note": "A (%.0f MiB) copied from pinned host memory to the lane's device buffer before each compression, copies and compressions of different lanes overlapping" % (8.0 * m * n / 2 ** 20)}
 
     # ---- stage / kernel timers: HIP events on lane 0's own stream, eager launches --------
     # one (reset -> call -> read) cycle per sample, so every launch is seen individually; the samples taken before
@@ -297,31 +318,61 @@ def main():
 
     fl, by = work_model(m, n, k, p, with_id)
     total_flops = sum(fl.values())
+
+    def sketch_kernel_name():
+        # the instantiation the library launches for the sketch shape: issue that product once on lane 0 and ask
+        fn = lib.rc_last_gemm_kernel_name
+        fn.restype = ctypes.c_char_p
+        fn.argtypes = [ctypes.c_void_p]
+        with torch.cuda.stream(lanes[0]["stream"]):
+            om = torch.empty((n, l), dtype=dt, device="cuda")
+            y = torch.empty((m, l), dtype=dt, device="cuda")
+            lanes[0]["ctx"].call("rc_matmat_f64", _lib.mat(lanes[0]["a"]), _lib.mat(om), _lib.mat(y))
+        lanes[0]["ctx"].synchronize()
+        nm = fn(lanes[0]["ctx"]._h)
+        return nm.decode() if nm else None
+
     # the library runs the skinny-N sketch as the transposed problem (M = l), the timer carries that shape
     key = f"kernel:k_gemm_mfma<f64> M={l} N={m} K={n}"
     if key not in prof:
         key = f"kernel:k_gemm_mfma<f64> M={m} N={l} K={n}"
     roof = None
     if key in prof and prof[key][1] > 0:
-        ms_launch = prof[key][0] / prof[key][1]
+        ms_gemm = prof[key][0] / prof[key][1]
+        # the deterministic split-K slab reduction is part of the same product: it is timed with it
+        red = [kk for kk in prof if kk.startswith("kernel:k_splitk_reduce M=%d N=%d " % (l, m)) or kk.startswith("kernel:k_splitk_reduce M=%d N=%d " % (m, l))]
+        ms_reduce = sum(prof[kk][0] / prof[kk][1] for kk in red)
+        ms_launch = ms_gemm + ms_reduce
         achieved = fl["sketch_gemm"] / (ms_launch * 1e-3) / 1e12
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
-        if os.path.exists(tpath):
+        # HBM bytes per launch from the PMC passes (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE, tools/pmc_gemm.sh); the
+        # record names the kernel instantiation it was taken on, so a stale figure is detectable: it is reported only when
+        # that instantiation is the one the library still launches for this shape (rc_gemm_kernel_name)
+        traffic, traffic_src = None, None
+        for tname in ("r02_pmc_traffic.json", "r01_pmc_traffic.json"):
+            tpath = os.path.join(ROOT, "profiles", tname)
+            if not os.path.exists(tpath):
+                continue
             try:
-                traffic = json.load(open(tpath)).get("k_gemm_mfma_sketch_bytes_per_launch")
+                rec = json.load(open(tpath))
             except Exception:
-                traffic = None
+                continue
+            traffic_src = {"file": "profiles/" + tname, "source": rec.get("source"), "kernel": rec.get("kernel")}
+            cur = sketch_kernel_name()
+            if rec.get("kernel") is None or cur is None or rec.get("kernel") == cur:
+                traffic = rec.get("k_gemm_mfma_sketch_bytes_per_launch")
+            else:
+                traffic_src["stale"] = "PMC pass was taken on %s, the library now launches %s" % (rec.get("kernel"), cur)
+            break
         roof = {"bound": "mfma", "kernel": "k_gemm_f64q (sketch Y = A*Omega, %dx%dx%d, run as Y^T = Omega^T A^T)" % (m, l, n), "achieved": round(achieved, 3),
-                "peak": F64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / F64_MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
-                "avg_launch_ms": round(ms_launch, 4), "launches_timed": len(samples),
+                "peak": F64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / F64_MFMA_PEAK_TFLOPS, 4), "traffic": traffic, "traffic_source": traffic_src,
+                "avg_launch_ms": round(ms_launch, 4), "gemm_ms": round(ms_gemm, 4), "splitk_reduce_ms": round(ms_reduce, 4), "launches_timed": len(samples),
                 "launch_ms_samples_before_timed_region": [round(x[key], 4) for x in prof_before if key in x],
                 "launch_ms_samples_after_timed_region": [round(x[key], 4) for x in samples_after if key in x],
                 "flops_per_launch": fl["sketch_gemm"], "hbm_gbs_algorithmic": round(8.0 * m * n / (ms_launch * 1e-3) / 1e9, 1),
                 "method": "HIP events on the launching stream around each launch (rc_profile_*): median of the eager single-stream samples taken right before and right after the timed region"}
 
     # ---- CPU baseline: the oracle in the reference's call shape on this box's host cores --
-    cpu = None
+    cpu = cpu_gemm = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         from oracle import ref_lapack as o
 
@@ -337,6 +388,13 @@ def main():
         for _ in range(args.cpu_baseline_reps):
             o.rsvd_id_reference_shape(a_h, om_h, k, faithful=True)
         tc = (time.perf_counter() - tc0) / args.cpu_baseline_reps
+        tg0 = time.perf_counter()
+        o.rsvd_id_reference_shape(a_h, om_h, k, faithful=False)
+        tg = time.perf_counter() - tg0
+        cpu_gemm = {"value": round(1.0 / tg, 4), "unit": "compressions/s", "cores": cores, "kind": "port",
+                    "sample": "1 compression of the same matrix with the two operator products as single GEMMs (numpy @ / OpenBLAS dgemm) "
+                              "instead of the reference's per-column gemv loops; everything else as cpu_baseline; %.2f s" % tg,
+                    "seconds_per_compression": round(tg, 3)}
         cpu = {"value": round(1.0 / tc, 4), "unit": "compressions/s", "cores": cores, "kind": "port",
                "sample": "%d compression(s) of the same 8192x8192 f64 matrix, rSVD+ID, reference call shape "
                          "(per-column gemv loops for A*Omega and A^H*Q, ?geqp3+?orgqr, ?gesdd, per-column ?trtrs) via oracle/ref_lapack.py "
@@ -344,7 +402,7 @@ def main():
                "seconds_per_compression": round(tc, 3)}
 
     if rank == 0:
-        steps_total = args.steps * world
+        steps_total = args.steps * S * world   # compressions in the timed region, all ranks
         value = steps_total / elapsed
         stage_ms = {kk: round(v[0] / max(v[1], 1), 4) for kk, v in sorted(prof.items()) if kk.startswith(("stage:", "op:", "info:"))}
         line = {
@@ -362,6 +420,7 @@ def main():
             "dtype": "f64",
             "data": "synthetic",
             "config": {"workload": "cfg3: %dx%d f64 dense N(0,1), rank-%d rSVD%s, p=%d (BASELINE.json configs[2])" % (m, n, k, "+ID" if with_id else "", p),
+                       "compressions_per_step": S, "compressions_timed": steps_total,
                        "streams_per_gpu": S, "hipgraph": not args.no_graph, "parallelism": "independent matrices, %d per GPU in flight" % S},
             "gb_per_s": round(value * by / 1e9, 2),
             "tflops_algorithmic": round(value * total_flops / 1e12, 3),
@@ -370,6 +429,8 @@ def main():
             "flops_per_compression": total_flops,
             "roofline": roof,
             "cpu_baseline": cpu,
+            "cpu_baseline_gemm_form": cpu_gemm,
+            "value_including_h2d": h2d,
             "stage_ms_single_stream_eager": stage_ms,
         }
         print(json.dumps(line), flush=True)

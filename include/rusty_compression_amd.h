@@ -79,6 +79,11 @@ rc_status rc_set_stream(rc_context *ctx, void *hip_stream);
 rc_status rc_stream_create(int32_t device, void **hip_stream);
 rc_status rc_stream_destroy(int32_t device, void *hip_stream);
 rc_status rc_synchronize(rc_context *ctx);
+/* Wait for n contexts at once: a completion event is recorded on EVERY context's stream before the first wait.  A host
+ * that keeps dozens of independent compressions in flight (one context + stream each) should use this instead of
+ * rc_synchronize context by context: stream-by-stream waits returned after max(259 ms, work) on ROCm 7.2 when more
+ * than ~28 streams held work ("Completion waits").  No reference counterpart (the reference is synchronous). */
+rc_status rc_synchronize_all(rc_context *const *ctxs, int32_t n);
 /* Pre-size the internal workspace arena (bytes); optional, it grows on demand. */
 rc_status rc_reserve_workspace(rc_context *ctx, size_t bytes);
 const char *rc_last_error_message(const rc_context *ctx);
@@ -141,14 +146,28 @@ rc_status rc_profile_reset(rc_context *ctx);
 rc_status rc_profile_count(rc_context *ctx, int32_t *n);
 rc_status rc_profile_get(rc_context *ctx, int32_t i, char *name, int32_t name_cap, double *total_ms, int64_t *calls);
 
+/* Instantiation of the most recent GEMM launch of this context, spelled as rocprofv3 prints it
+ * (e.g. "k_gemm_f64q<1,1,136,256,16,2,4,2,0,0>"): lets bench.py tell whether a committed PMC traffic figure was taken on
+ * the kernel that still runs.  Diagnostic, no reference counterpart. */
+const char *rc_last_gemm_kernel_name(const rc_context *ctx);
+
 /* ------------------------------------------------------- random_matrix.rs -- */
-/* RandomMatrix::random_gaussian (src/random_matrix.rs:21, :120-125): i.i.d.
- * N(0,1), drawn in f64 and cast.  Element (i, j) is sample number i*cols + j
- * (row-major draw order, as the reference fills) of the Philox4x32-10 stream
- * (seed, offset); the reference's rand/rand_distr ziggurat stream cannot be
- * reproduced sample-for-sample, so parity tests pass Omega explicitly. */
+/* RandomMatrix::random_gaussian (src/random_matrix.rs:21, :120-125): i.i.d. N(0,1), drawn in f64 and cast to T,
+ * filled in row-major order.  The reference's rand 0.8 / rand_distr 0.4 ziggurat stream is sequential host code with no
+ * pinned version, so it cannot be reproduced sample for sample; parity tests pass Omega explicitly.  The stream of THIS
+ * ABI is defined here (and restated in oracle/philox.py, which the GPU kernel is tested against bit for bit):
+ *   Philox4x32-10 (Salmon et al., SC'11), key = (seed & 0xffffffff, seed >> 32), counter = (b & 0xffffffff, b >> 32, 0, 0)
+ *   for block b -> words w0..w3;  a = w0 << 32 | w1,  b' = w2 << 32 | w3;
+ *   u1 = ((a >> 11) + 1) * 2^-53 in (0, 1],  u2 = (b' >> 11) * 2^-53 in [0, 1);
+ *   z0 = sqrt(-2 ln u1) cos(2 pi u2),  z1 = sqrt(-2 ln u1) sin(2 pi u2)   (Box-Muller);
+ *   number e of the stream (seed, offset) is z_{(offset + e) & 1} of block (offset + e) >> 1;
+ *   element (i, j) of out is number i * cols + j;  the f32 variant is the cast of the f64 value. */
 rc_status rc_random_gaussian_f64(rc_context *ctx, rc_matrix out, uint64_t seed, uint64_t offset);
 rc_status rc_random_gaussian_f32(rc_context *ctx, rc_matrix out, uint64_t seed, uint64_t offset);
+/* The raw uint32 words of the same Philox stream (word w = w_{w & 3} of block w >> 2), n words from word_offset into
+ * device memory `out`: the integer generator is checkable bit for bit against oracle/philox.py and Random123's
+ * known-answer vectors.  No reference counterpart. */
+rc_status rc_random_bits_u32(rc_context *ctx, uint32_t *out, int64_t n, uint64_t seed, uint64_t word_offset);
 
 /* --------------------------------------------------------------- types.rs -- */
 /* MatMat::matmat for dense matrices (src/types.rs:58-71, :103-121): Y = A X.

@@ -12,7 +12,7 @@ from .col_interp_decomp import ColumnID  # noqa: F401
 from .permutation import (MatrixPermutationMode, VectorPermutationMode, apply_permutation,  # noqa: F401
                           invert_permutation_vector)
 from .qr import LQ, QR, pivoted_lq, pivoted_qr  # noqa: F401
-from .random_matrix import (Rng, random_approximate_low_rank_matrix, random_gaussian,  # noqa: F401
+from .random_matrix import (Rng, random_approximate_low_rank_matrix, random_bits_u32, random_gaussian,  # noqa: F401
                             random_orthogonal_matrix)
 from .random_sampling import (max_col_norm, sample_range_adaptive, sample_range_by_rank,  # noqa: F401
                               sample_range_power_iteration)
@@ -24,7 +24,7 @@ from .types import CompressionType, conj_matmat, dot, matmat, rel_diff_fro, rel_
 __all__ = [
     "QR", "LQ", "SVD", "ColumnID", "RowID", "TwoSidedID", "CompressionType", "Rng",
     "MatrixPermutationMode", "VectorPermutationMode", "apply_permutation", "invert_permutation_vector",
-    "random_gaussian", "random_orthogonal_matrix", "random_approximate_low_rank_matrix",
+    "random_gaussian", "random_bits_u32", "random_orthogonal_matrix", "random_approximate_low_rank_matrix",
     "sample_range_by_rank", "sample_range_power_iteration", "sample_range_adaptive", "max_col_norm",
     "matmat", "conj_matmat", "dot", "rel_diff_fro", "rel_diff_l2", "pivoted_qr", "pivoted_lq", "compute_svd",
     "RustyCompressionError", "LinalgError", "CompressionError", "LayoutError", "PivotedQRError", "HipRuntimeError",

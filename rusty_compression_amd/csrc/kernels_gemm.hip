@@ -583,6 +583,11 @@ static void launch_cfg(rc_context *c, GemmArgs<T> g) {
         attr_set[c->device & 63] = true;
     }
     {
+        char nm[128];
+        snprintf(nm, sizeof(nm), "k_gemm_mfma<%s,%d,%d,%d,%d,%d,%d,%d,%d,%d>", sizeof(T) == 8 ? "double" : "float", ALAY, BLAY, BM, BN, BK, WM, WN, VEC, NBUF);
+        c->last_gemm_kernel = nm;
+    }
+    {
         ProfScope ps(c, "kernel:k_gemm_mfma<%s> M=%lld N=%lld K=%lld", sizeof(T) == 8 ? "f64" : "f32", (long long)g.M, (long long)g.N, (long long)g.K);
         hipLaunchKernelGGL(kern, dim3((unsigned)tiles, (unsigned)splits), dim3(NT), lds, c->stream, g);
     }
@@ -623,6 +628,11 @@ static void launch_f64q(rc_context *c, GemmArgs<double> g) {
     if (lds > 48 * 1024 && !attr_set[c->device & 63]) {
         RC_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_set[c->device & 63] = true;
+    }
+    {
+        char nm[128];
+        snprintf(nm, sizeof(nm), "k_gemm_f64q<%d,%d,%d,%d,%d,%d,%d,%d,%d,%d>", ALAY, BLAY, BM, BN, BK, WM, WN, VEC, ORIENT, GLDS);
+        c->last_gemm_kernel = nm;
     }
     {
         ProfScope ps(c, "kernel:k_gemm_mfma<f64> M=%lld N=%lld K=%lld", (long long)g.M, (long long)g.N, (long long)g.K);

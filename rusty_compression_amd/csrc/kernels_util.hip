@@ -54,6 +54,27 @@ __global__ __launch_bounds__(256) void k_fill_gaussian(Mat<T> out, uint64_t seed
     }
 }
 
+// raw words of the same stream (word w = w_{w & 3} of block w >> 2): lets a test compare the integer generator bit for bit
+__global__ __launch_bounds__(256) void k_philox_words(uint32_t *out, int64_t n, uint64_t seed, uint64_t word_offset) {
+    const uint64_t first = word_offset >> 2;
+    const int64_t nblk = (int64_t)(((word_offset + (uint64_t)n + 3) >> 2) - first);
+    for (int64_t bi = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; bi < nblk; bi += (int64_t)gridDim.x * blockDim.x) {
+        const uint64_t blk = first + (uint64_t)bi;
+        uint32_t ctr[4] = {(uint32_t)blk, (uint32_t)(blk >> 32), 0u, 0u};
+        philox4x32_10(ctr, (uint32_t)seed, (uint32_t)(seed >> 32));
+#pragma unroll
+        for (int h = 0; h < 4; ++h) {
+            const int64_t e = (int64_t)(4 * blk + (uint64_t)h) - (int64_t)word_offset;
+            if (e >= 0 && e < n) out[e] = ctr[h];
+        }
+    }
+}
+void philox_words(rc_context *c, uint32_t *out, int64_t n, uint64_t seed, uint64_t word_offset) {
+    if (n <= 0) return;
+    int grid = (int)std::min<int64_t>(cdiv((n + 6) / 4, 256), 4096);
+    hipLaunchKernelGGL(k_philox_words, dim3(grid), dim3(256), 0, c->stream, out, n, seed, word_offset);
+}
+
 template <typename T>
 void fill_gaussian(rc_context *c, Mat<T> out, uint64_t seed, uint64_t offset) {
     if (out.empty()) return;

@@ -148,6 +148,8 @@ void rc_context::release_all() {
     aux_stream = nullptr;
     if (pinned) (void)hipHostFree(pinned);
     pinned = nullptr;
+    if (sync_ev) (void)hipEventDestroy(sync_ev);
+    sync_ev = nullptr;
 }
 
 namespace {
@@ -791,6 +793,30 @@ rc_status rc_synchronize(rc_context *ctx) {
     return RC_OK;
 }
 
+// Record a completion event behind the last command of EVERY context first, wait for them afterwards.  With dozens of
+// busy streams a stream-by-stream hipStreamSynchronize returned after max(259 ms, work) on this stack (DESIGN.md,
+// "Completion waits"); with an event on every stream before the first wait the waits come back on time.
+rc_status rc_synchronize_all(rc_context *const *ctxs, int32_t n) {
+    if (n < 0 || (n > 0 && !ctxs)) return RC_INVALID_ARGUMENT;
+    rc_status st = RC_OK;
+    for (int32_t i = 0; i < n; ++i) {
+        rc_context *c = ctxs[i];
+        if (!c) return RC_INVALID_ARGUMENT;
+        DeviceGuard dg(c->device);
+        if (!c->sync_ev && hipEventCreateWithFlags(&c->sync_ev, hipEventDisableTiming) != hipSuccess) { c->last_error = "hipEventCreate failed"; return RC_RUNTIME_ERROR; }
+        hipError_t e = hipEventRecord(c->sync_ev, c->stream);
+        if (e != hipSuccess) { c->last_error = hipGetErrorString(e); st = RC_RUNTIME_ERROR; }
+    }
+    for (int32_t i = 0; i < n; ++i) {
+        rc_context *c = ctxs[i];
+        DeviceGuard dg(c->device);
+        hipError_t e = hipEventSynchronize(c->sync_ev);
+        if (e == hipSuccess && c->aux_stream) e = hipStreamSynchronize(c->aux_stream);
+        if (e != hipSuccess) { c->last_error = hipGetErrorString(e); st = RC_RUNTIME_ERROR; }
+    }
+    return st;
+}
+
 rc_status rc_reserve_workspace(rc_context *ctx, size_t bytes) {
     if (!ctx) return RC_INVALID_ARGUMENT;
     DeviceGuard dg(ctx->device);
@@ -936,6 +962,15 @@ rc_status rc_profile_get(rc_context *ctx, int32_t i, char *name, int32_t name_ca
     if (total_ms) *total_ms = it->second.ms;
     if (calls) *calls = it->second.calls;
     return RC_OK;
+}
+
+const char *rc_last_gemm_kernel_name(const rc_context *ctx) { return ctx ? ctx->last_gemm_kernel.c_str() : ""; }
+
+rc_status rc_random_bits_u32(rc_context *ctx, uint32_t *out, int64_t n, uint64_t seed, uint64_t word_offset) {
+    return guarded(ctx, [&] {
+        RC_REQUIRE(n >= 0 && (out != nullptr || n == 0), RC_INVALID_ARGUMENT, "random_bits: null output");
+        philox_words(ctx, out, n, seed, word_offset);
+    });
 }
 
 rc_status rc_invert_permutation(rc_context *ctx, const int64_t *perm, int64_t n, int64_t *inverse) {

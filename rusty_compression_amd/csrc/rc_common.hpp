@@ -85,6 +85,7 @@ struct rc_context {
     int device = 0;
     hipStream_t stream = nullptr;
     std::string last_error;
+    std::string last_gemm_kernel;  // instantiation of the most recent GEMM launch, spelled as rocprofv3 prints it (rc_last_gemm_kernel_name)
 
     // Workspace arena.  Every C-ABI call resets the bump pointer on entry; all
     // work is ordered on `stream`, so a later call may reuse the bytes of an
@@ -107,6 +108,7 @@ struct rc_context {
     struct ArenaState { char *base = nullptr; size_t size = 0, off = 0, high = 0; std::vector<void *> overflow; } aux_arena;
     void swap_arena();
     int opt_fork = 0;  // 1: rc_rsvd_id runs its two branches side by side (lower latency; measured LOWER throughput with many graphs in flight)
+    hipEvent_t sync_ev = nullptr;       // rc_synchronize_all: one completion event per context
     void *pinned = nullptr;             // small pinned host buffer for scalar read-backs
     size_t pinned_size = 0;
 
@@ -182,6 +184,7 @@ struct ArenaMark {
 // kernel launchers (defined in the kernels_*.hip translation units)
 // ---------------------------------------------------------------------------
 template <typename T> void fill_gaussian(rc_context *c, Mat<T> out, uint64_t seed, uint64_t offset);
+void philox_words(rc_context *c, uint32_t *out, int64_t n, uint64_t seed, uint64_t word_offset);
 template <typename T> void copy_mat(rc_context *c, Mat<T> src, Mat<T> dst);                 // dst = src (any strides)
 template <typename T> void fill_identity(rc_context *c, Mat<T> dst);                        // dst = [I | 0] / [I ; 0]
 template <typename T> void fill_zero(rc_context *c, Mat<T> dst);

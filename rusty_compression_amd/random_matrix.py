@@ -32,6 +32,14 @@ def random_gaussian(dimension, rng: Rng, dtype=torch.float64) -> torch.Tensor:
     return out
 
 
+def random_bits_u32(n: int, seed: int, word_offset: int = 0) -> torch.Tensor:
+    """Raw uint32 words of the Philox4x32-10 stream behind `random_gaussian` (rc_random_bits_u32), as an int64 tensor."""
+    out = torch.empty(int(n), dtype=torch.int32, device="cuda")
+    _lib.default_context().call("rc_random_bits_u32", ctypes.c_void_p(out.data_ptr()), ctypes.c_int64(int(n)),
+                                ctypes.c_uint64(int(seed) & 0xFFFFFFFFFFFFFFFF), ctypes.c_uint64(int(word_offset)))
+    return out.to(torch.int64) & 0xFFFFFFFF
+
+
 def random_orthogonal_matrix(dimension, rng: Rng, dtype=torch.float64) -> torch.Tensor:
     """src/random_matrix.rs:35-56: U of the thin SVD of a Gaussian (rows orthonormal if wide)."""
     from .svd import SVD

@@ -161,3 +161,35 @@ def test_tolerance_not_reachable_is_a_compression_error():
         o.QR.compute_from(a).compress("ADAPTIVE", 1e-3)
     with pytest.raises(AssertionError):
         o.QR.compute_from(a).compress("ADAPTIVE", 1.5)
+
+
+# ---------------------------------------------------------------- Gaussian stream (a1): oracle/philox.py
+def test_philox_restatement_reproduces_random123_known_answers_and_golden():
+    """The integer generator behind rc_random_gaussian_* (ABI text: include/rusty_compression_amd.h, random_matrix.rs
+    section), restated in numpy, against Random123's published philox4x32-10 vectors and the committed golden."""
+    from oracle import philox as ph
+
+    g = golden("philox_stream.npz")
+    for ctr, key, want in zip(g["kat_ctr"], g["kat_key"], g["kat_out"]):
+        assert np.array_equal(ph.philox4x32_10(ctr[None, :], tuple(int(x) for x in key))[0], want)
+    for i, (seed, off) in enumerate(g["pairs"]):
+        assert np.array_equal(ph.words(int(seed), int(off), 4096), g[f"words_{i}"])
+        assert np.array_equal(ph.normals(int(seed), int(off), 4096), g[f"normals_{i}"])
+    # stream continuity and row-major draw order of the matrix form
+    a = ph.random_gaussian((10, 7), 7, 0)
+    b = ph.random_gaussian((5, 7), 7, 70)
+    assert np.array_equal(np.vstack([a, b]), ph.random_gaussian((15, 7), 7, 0))
+    assert np.array_equal(ph.random_gaussian((10, 7), 7, 0, np.float32), a.astype(np.float32))
+
+
+def test_philox_normals_are_normal():
+    from scipy import stats
+
+    from oracle import philox as ph
+
+    z = ph.normals(11, 0, 400000)
+    assert stats.kstest(z, "norm").pvalue > 1e-3
+    # chi-square on 64 equiprobable bins
+    edges = stats.norm.ppf(np.linspace(0, 1, 65)[1:-1])
+    cnt = np.bincount(np.searchsorted(edges, z), minlength=64)
+    assert stats.chisquare(cnt).pvalue > 1e-3
