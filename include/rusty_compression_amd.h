@@ -133,9 +133,11 @@ rc_status rc_graph_destroy(rc_context *ctx, void *graph_exec);
  * throughput measured lower (680 vs 913 compressions/s), hence opt-in. */
 enum { RC_OPT_TALL_SKINNY_FAST_PATH = 1, RC_OPT_WIDE_LAZY_QRCP = 2, RC_OPT_WIDE_COOP_QRCP = 3, RC_OPT_POWER_ITERATION_FIXED = 4, RC_OPT_FORK_BRANCHES = 5 };
 rc_status rc_set_option(rc_context *ctx, int32_t option, int64_t value);
-/* Health word (read and cleared): bit 0 non-positive Cholesky pivot, bit 1 first CholeskyQR pass too far from orthonormal
- * (both: tall-skinny fast path inside a graph), bit 2 cooperative short-wide QR could not get its workgroups resident,
- * bit 3 the right-vector workgroup of the Jacobi SVD never saw its producer within the spin bound.  0 = every result stands. */
+/* Health word (read and cleared), OR of: 1 non-positive Cholesky pivot, 2 first CholeskyQR pass too far from orthonormal
+ * (both: tall-skinny fast path inside a graph, where no fallback is possible), 4 cooperative short-wide QR could not get
+ * its workgroups resident, 8 the right-vector workgroup of the Jacobi SVD never saw its producer within the spin bound,
+ * 16 a Jacobi SVD used up its sweep budget before converging (eager calls as well: the factors are then accurate to the
+ * last sweep's rotation angles only).  0 = every result stands. */
 rc_status rc_get_health(rc_context *ctx, int32_t *word);
 
 /* Stage / kernel timers: HIP events recorded on the context's stream around the

@@ -40,6 +40,11 @@ def column_id_rank(a: torch.Tensor, k: int) -> Tuple[torch.Tensor, torch.Tensor,
     return c, z, ind
 
 
+def packed_bytes(m: int, n: int, k: int, elem_size: int) -> int:
+    """Bytes one matrix's factors take in the packed buffer: C (m x k) | Z (k x n) | col_ind (n int64)."""
+    return (m * k + k * n) * elem_size + n * 8
+
+
 def pack_factors(factors: Sequence[Tuple[torch.Tensor, torch.Tensor, torch.Tensor]]) -> torch.Tensor:
     """[(C, Z, col_ind), ...] -> one flat buffer of the factors' dtype (indices bit-cast, exact)."""
     parts = []

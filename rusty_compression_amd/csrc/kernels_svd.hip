@@ -246,6 +246,7 @@ __global__ __launch_bounds__(LPP == 16 ? 1024 : 512) void k_jacobi_lds(Mat<T> g,
     asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(jlast)::"memory");
 #endif
     int sweep = 0;
+    bool converged = false;
     for (; sweep < max_sweeps; ++sweep) {
         if (tid == 0) sh_rot = 0;
         if (CN) {
@@ -313,10 +314,14 @@ __global__ __launch_bounds__(LPP == 16 ? 1024 : 512) void k_jacobi_lds(Mat<T> g,
                                 gq[i] = rot.s * a[e] + rot.c * b[e];
                             }
                         }
-                        // flag 2 = some pair rotated by an angle with cos > sqrt(tol) / 4 (9e-9 in f64): only then is another
-                        // sweep needed -- the convergence is quadratic, smaller angles leave angles << tol behind, so the
-                        // sweep that finds nothing larger is the last one (no separate all-quiet verification sweep)
-                        if (ll == 0 && apq * apq > tol * (T)0.0625 * app * aqq) sh_rot = 2;  // plain store: every writer writes 2
+                        // flag 2 = another sweep is needed.  A rotation by the angle (c, s) of a pair whose cosine was g leaves
+                        // at most |s| * (largest cosine of this sweep) behind in pairs that were already annihilated, so a sweep
+                        // may be the last one only if every rotation in it had BOTH a small cosine (g <= sqrt(tol) / 4, 9e-9 in
+                        // f64) AND a small angle (|s| <= 4 sqrt(tol)): for well separated singular values the second follows
+                        // from the first (quadratic convergence), for clustered / repeated ones (sigma_p ~ sigma_q: the angle is
+                        // O(1) however small g is) it does not, and such sweeps are followed by another one until an all-quiet
+                        // or all-small sweep has been seen
+                        if (ll == 0 && (apq * apq > tol * (T)0.0625 * app * aqq || rot.s * rot.s > (T)16 * tol)) sh_rot = 2;  // plain store: every writer writes 2
                     }
                 }
                 RC_JTICK(3)  // rotation applied, written back (LDS queue drained by the stamp)
@@ -330,8 +335,10 @@ __global__ __launch_bounds__(LPP == 16 ? 1024 : 512) void k_jacobi_lds(Mat<T> g,
         }
         const int rotated = sh_rot;
         __syncthreads();
-        if (!(RC_JAC_ABL & 32) && rotated < 2) { ++sweep; break; }
+        if (!(RC_JAC_ABL & 32) && rotated < 2) { ++sweep; converged = true; break; }
     }
+    // max_sweeps exhausted with rotations still above the thresholds: reported, never silent (health bit 4, value 16)
+    if (tid == 0 && !converged && !(RC_JAC_ABL & 32) && health) atomicOr(health, 16);
 #ifdef RC_JAC_TIMING
     if (tid == 0) {
         for (int k2 = 0; k2 < 6; ++k2) g_jac_dbg[k2] = jt[k2];
@@ -502,6 +509,9 @@ __global__ __launch_bounds__(256) void k_jacobi_round(Mat<T> g, Mat<T> v, int r,
     }
     if (lane == 0) state[0] = 1;
 }
+__global__ void k_jacobi_check(const int *state, int *health) {
+    if (threadIdx.x == 0 && !state[1]) atomicOr(health, 16);  // sweep budget exhausted before an all-quiet sweep
+}
 __global__ void k_jacobi_sweep_end(int *state) {
     if (threadIdx.x != 0 || state[1]) return;
     state[2] += 1;
@@ -571,6 +581,7 @@ static void jacobi_global(rc_context *c, Mat<T> g, Mat<T> v, Mat<T> uc, T *s, Ma
             if (h[1]) break;
         }
     }
+    hipLaunchKernelGGL(k_jacobi_check, dim3(1), dim3(64), 0, c->stream, state, c->health_word());
     hipLaunchKernelGGL(k_jacobi_norms<T>, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, c->stream, g, sig);
     hipLaunchKernelGGL(k_jacobi_rank<T>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, n, sig, order, s);
     hipLaunchKernelGGL(k_jacobi_emit<T>, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, c->stream, g, v, sig, order, uc, vc);
@@ -601,7 +612,7 @@ static void launch_lds_impl(rc_context *c, Mat<T> g, Mat<T> uc, T *s, Mat<T> vc,
         hipLaunchKernelGGL(kern, dim3(2), dim3(threads), lds, c->stream, g, log, sweeps, uc, s, order, max_sweeps, 1, vsync, chk, c->epoch_word(), vc, c->health_word(), ld);
     } else {
         hipLaunchKernelGGL(kern, dim3(1), dim3(threads), lds, c->stream, g, log, sweeps, uc, s, order, max_sweeps, 0, (unsigned *)nullptr, (unsigned long long *)nullptr,
-                           (unsigned *)nullptr, vc, (int *)nullptr, ld);
+                           (unsigned *)nullptr, vc, c->health_word(), ld);
     }
     static const int rpw_env = [] { const char *e = getenv("RC_REPLAY_RPW"); return e ? atoi(e) : 1; }();
     const int rpw = (N / 2 <= 64) ? (rpw_env == 2 || rpw_env == 4 ? rpw_env : 1) : 1;  // rows per wave: 1 measured best (913 vs 903 compressions/s at 4)

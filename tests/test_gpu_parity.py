@@ -288,6 +288,35 @@ def test_svd_cores_beyond_the_lds_limit(dtype, shape):
         assert np.abs(vt[:lead] @ vt[:lead].T - np.eye(lead)).max() <= (1e-11 if f64 else 1e-4)
 
 
+@pytest.mark.parametrize("shape", [(128, 128), (100, 50), (50, 100), (133, 133), (300, 40)])
+def test_svd_of_clustered_and_repeated_singular_values(shape):
+    """Clustered / (near-)equal singular values: a rotation between two such columns has an O(1) angle however small the
+    columns' cosine is, so the 'last sweep' shortcut of the Jacobi kernel must not fire on it.  ?gesdd delivers
+    orthonormal factors to ~1e-15 here and the reference's f64 tests assume 1e-12 (src/svd.rs:214-223)."""
+    from rusty_compression_amd import _lib
+
+    m, n = shape
+    r = min(m, n)
+    rng = np.random.default_rng(m * 1000 + n)
+    qa = np.linalg.qr(rng.standard_normal((m, r)))[0]
+    qb = np.linalg.qr(rng.standard_normal((n, r)))[0]
+    cases = {
+        "1 + 1e-9 r": (qa * (1.0 + 1e-9 * rng.standard_normal(r))) @ qb.T,
+        "all equal": qa @ qb.T,
+        "two clusters": (qa * np.where(np.arange(r) % 2 == 0, 1.0, 0.5 + 1e-12 * np.arange(r))) @ qb.T,
+    }
+    if m == n:
+        cases["I + 1e-9 E"] = np.eye(n) + 1e-9 * rng.standard_normal((n, n))
+    for name, a in cases.items():
+        u, s, vt = (npy(t) for t in rc.compute_svd(a))
+        so = o.compute_svd(a)[1]
+        assert np.abs(s - so).max() <= 1e-12 * so[0], name
+        assert np.abs(u.T @ u - np.eye(r)).max() <= 1e-12, (name, np.abs(u.T @ u - np.eye(r)).max())
+        assert np.abs(vt @ vt.T - np.eye(r)).max() <= 1e-12, (name, np.abs(vt @ vt.T - np.eye(r)).max())
+        assert rel((u * s) @ vt, a) <= 1e-12, name
+    assert _lib.default_context().get_health() == 0  # no sweep budget was exhausted
+
+
 @pytest.mark.parametrize("dtype", [np.float64, np.float32])
 def test_degenerate_shapes_and_zero_matrices(dtype):
     """1 x 1, single rows / columns, all-zero inputs (every reflector is the identity: tau = 0) and rank-1 inputs
@@ -662,7 +691,9 @@ def test_svd_of_tall_and_wide_matrices_through_both_paths(dtype):
 
 
 def test_headline_size_sketch_matches_the_oracle():
-    """cfg2 / cfg3 shapes with device-generated inputs; oracle in GEMM form on the same bits."""
+    """cfg2 / cfg3 shapes with device-generated inputs; oracle in GEMM form on the same bits.  Every factor of the chain is
+    held to the oracle: range basis, S, U S V^T, the FULL permutation (a k x n ?geqp3 performs exactly k steps, so the tail
+    ind[k:] is the deterministic swap order), R, Q, and the column ID built from them."""
     for (n, k) in ((4096, 64), (8192, 128)):
         a = rc.random_gaussian((n, n), rc.Rng(n))
         om = rc.random_gaussian((n, k + 5), rc.Rng(1))
@@ -676,8 +707,131 @@ def test_headline_size_sketch_matches_the_oracle():
         assert rel(npy(svd.to_mat()), osv.to_mat()) <= 1e-10
         qr = rc.QR.compute_from_range_estimate(q, a)
         oqr = o.QR.compute_from_range_estimate(oq, an)
-        assert np.array_equal(npy(qr.ind)[:k], oqr.ind[:k])
+        assert np.array_equal(npy(qr.ind), oqr.ind)
         assert rel(npy(qr.r), oqr.r) <= 1e-10
+        assert rel(npy(qr.q), oqr.q) <= 1e-10
+        cid, ocid = qr.column_id(), oqr.column_id()
+        assert rel(npy(cid.c), ocid.c) <= 1e-10 and rel(npy(cid.z), ocid.z) <= 1e-9
+        assert np.array_equal(npy(cid.col_ind), ocid.col_ind)
+
+
+def _rsvd_id_buffers(m, n, k):
+    import ctypes
+
+    from rusty_compression_amd import _lib
+
+    mk = lambda r, c: torch.zeros((r, c), dtype=torch.float64, device="cuda")  # noqa: E731
+    b = dict(range_q=mk(m, k), u=mk(m, k), s=torch.zeros(k, dtype=torch.float64, device="cuda"), vt=mk(k, n), qr_q=mk(m, k), qr_r=mk(k, n),
+             qr_ind=torch.zeros(n, dtype=torch.int64, device="cuda"), id_c=mk(m, k), id_z=mk(k, n))
+    o_ = _lib.rc_rsvd_id_out(_lib.mat(b["range_q"]), _lib.mat(b["u"]), ctypes.c_void_p(b["s"].data_ptr()), _lib.mat(b["vt"]), _lib.mat(b["qr_q"]),
+                             _lib.mat(b["qr_r"]), ctypes.c_void_p(b["qr_ind"].data_ptr()), _lib.mat(b["id_c"]), _lib.mat(b["id_z"]))
+    return b, o_
+
+
+def test_cfg3_accuracy_bearing_input_through_the_fused_call_eager_and_graph_replayed():
+    """the second cfg3 input, A = U diag(geomspace(1e-10, 1, 8192)) V^T (reference recipe), so that the
+    <= 1e-10 factor-error target means something; through rc_rsvd_id_f64 eagerly and replayed from a hipGraph."""
+    import ctypes
+
+    from rusty_compression_amd import _lib
+
+    n, k, p = 8192, 128, 5
+    lib = _lib.lib()
+    st = torch.cuda.Stream()
+    with torch.cuda.stream(st):
+        ctx = _lib.Context(torch.cuda.current_device(), st.cuda_stream)
+        a = _decaying_matrix(n, 1e-10, torch.float64, 3)
+        om = rc.random_gaussian((n, k + p), rc.Rng(33))
+        st.synchronize()
+        eager, oe = _rsvd_id_buffers(n, n, k)
+
+        def run(o_):
+            ctx.call("rc_rsvd_id_f64", _lib.mat(a), ctypes.c_int64(k), ctypes.c_int64(p), _lib.mat(om), ctypes.c_uint64(0), ctypes.byref(o_))
+
+        run(oe)
+        ctx.synchronize()
+        rep, orep = _rsvd_id_buffers(n, n, k)
+        run(orep)
+        ctx.synchronize()
+        graph = ctypes.c_void_p(None)
+        ctx.check(lib.rc_graph_begin_capture(ctx._h))
+        run(orep)
+        ctx.check(lib.rc_graph_end_capture(ctx._h, ctypes.byref(graph)))
+        for t in rep.values():
+            t.zero_()
+        ctx.check(lib.rc_graph_launch(ctx._h, graph))
+        ctx.synchronize()
+        assert ctx.get_health() == 0
+        for key in eager:
+            assert torch.equal(eager[key], rep[key]), key
+        ctx.check(lib.rc_graph_destroy(ctx._h, graph))
+        an, omn = npy(a), npy(om)
+        oq = o.sample_range_by_rank(an, k, p, lambda s_: omn)
+        osv = o.SVD.compute_from_range_estimate(oq, an)
+        oqr = o.QR.compute_from_range_estimate(oq, an)
+        ocid = oqr.column_id()
+        g = {kk: npy(v) for kk, v in eager.items()}
+        assert rel(g["range_q"], oq) <= 1e-10
+        assert np.abs(g["s"] - osv.s).max() / osv.s[0] <= 1e-12
+        assert rel((g["u"] * g["s"]) @ g["vt"], osv.to_mat()) <= 1e-10
+        assert np.array_equal(g["qr_ind"], oqr.ind)
+        assert rel(g["qr_r"], oqr.r) <= 1e-10 and rel(g["qr_q"], oqr.q) <= 1e-10
+        assert rel(g["id_c"], ocid.c) <= 1e-10 and rel(g["id_z"], ocid.z) <= 1e-9
+        # factor error vs the CPU reference path (north_star: <= 1e-10) and the approximation error itself
+        err = np.linalg.norm(an - (g["u"] * g["s"]) @ g["vt"]) / np.linalg.norm(an)
+        oerr = np.linalg.norm(an - osv.to_mat()) / np.linalg.norm(an)
+        assert abs(err - oerr) <= 1e-10
+        ctx.close()
+
+
+def test_graph_mode_reports_an_ill_conditioned_sketch_and_eager_mode_falls_back():
+    """Negative test of the captured fast paths: a sketch Y = A Omega with cond(Y)^2 eps >> 1 cannot go through
+    CholeskyQR2.  Inside a hipGraph no fallback is possible -- the replay must raise health bits 1 / 2; the eager call on
+    the same input must fall back to the Householder chain and match the oracle."""
+    import ctypes
+
+    from rusty_compression_amd import _lib
+
+    m = n = 2048
+    k, p = 32, 5
+    lib = _lib.lib()
+    rng = np.random.default_rng(77)
+    u = np.linalg.qr(rng.standard_normal((m, 64)))[0]
+    v = np.linalg.qr(rng.standard_normal((n, 64)))[0]
+    sig = np.concatenate([np.geomspace(1.0, 1e-11, k + p), np.full(64 - k - p, 1e-12)])   # cond(Y) ~ 1e11: cond^2 eps ~ 1e6
+    an = (u * sig) @ v.T
+    omn = rng.standard_normal((n, k + p))
+    st = torch.cuda.Stream()
+    with torch.cuda.stream(st):
+        ctx = _lib.Context(torch.cuda.current_device(), st.cuda_stream)
+        a, om = torch.from_numpy(an).cuda(), torch.from_numpy(omn).cuda()
+        eager, oe = _rsvd_id_buffers(m, n, k)
+
+        def run(o_):
+            ctx.call("rc_rsvd_id_f64", _lib.mat(a), ctypes.c_int64(k), ctypes.c_int64(p), _lib.mat(om), ctypes.c_uint64(0), ctypes.byref(o_))
+
+        run(oe)   # eager: the certificate fails, the call falls back
+        ctx.synchronize()
+        assert ctx.get_health() == 0
+        oq = o.sample_range_by_rank(an, k, p, lambda s_: omn)
+        osv = o.SVD.compute_from_range_estimate(oq, an)
+        g = {kk: npy(t) for kk, t in eager.items()}
+        assert np.abs(g["range_q"].T @ g["range_q"] - np.eye(k)).max() <= 1e-12
+        assert rel(g["range_q"][:, :8], oq[:, :8]) <= 1e-9          # later columns are ill-determined (sigma_j / sigma_1 down to 1e-10)
+        assert np.abs(g["s"] - osv.s).max() / osv.s[0] <= 1e-12
+        assert rel((g["u"] * g["s"]) @ g["vt"], osv.to_mat()) <= 1e-10
+        rep, orep = _rsvd_id_buffers(m, n, k)
+        graph = ctypes.c_void_p(None)
+        ctx.check(lib.rc_graph_begin_capture(ctx._h))
+        run(orep)
+        ctx.check(lib.rc_graph_end_capture(ctx._h, ctypes.byref(graph)))
+        ctx.check(lib.rc_graph_launch(ctx._h, graph))
+        ctx.synchronize()
+        h = ctx.get_health()
+        assert h & 3, f"health word {h}: an ill-conditioned captured CholeskyQR2 must raise bit 0 (value 1) or bit 1 (value 2)"
+        assert ctx.get_health() == 0   # read-and-clear
+        ctx.check(lib.rc_graph_destroy(ctx._h, graph))
+        ctx.close()
 
 
 # ---------------------------------------------------------------- BASELINE.json full sizes: size-independent properties
@@ -724,8 +878,21 @@ def test_cfg4_adaptive_two_sided_id_16384x4096():
     assert np.linalg.norm(npy(ts.x) - sub) <= 1e-5 * np.linalg.norm(npy(a))
 
 
-def test_cfg5_rank64_column_id_4096_f32():
-    """configs[4] unit of work: 4096 x 4096 f32, rank-64 column ID through the truncated factorization."""
+def _decaying_matrix(n, sigma_min, dtype, seed):
+    """The reference's test-matrix recipe (src/random_matrix.rs:70-93) at full size: A = U diag(geomspace(sigma_min, 1)) V^T with
+    U, V the orthogonal factors of seeded Gaussians.  Input generation only: the factors come from torch's QR."""
+    g = torch.Generator(device="cuda").manual_seed(seed)
+    u = torch.linalg.qr(torch.randn(n, n, dtype=torch.float64, device="cuda", generator=g)).Q
+    v = torch.linalg.qr(torch.randn(n, n, dtype=torch.float64, device="cuda", generator=g)).Q
+    sig = torch.logspace(0, float(np.log10(sigma_min)), n, dtype=torch.float64, device="cuda")
+    return ((u * sig) @ v.T).to(dtype).contiguous()
+
+
+def test_cfg5_rank64_column_id_4096_f32_gaussian():
+    """configs[4] unit of work: 4096 x 4096 f32 N(0,1), rank-64 column ID through the truncated factorization.  The column
+    norms of a Gaussian matrix agree to ~1 %, far inside what sgeqp3's f32 norm down-dating resolves after a few steps, so
+    the pivot ORDER legitimately depends on summation order here: the agreed prefix is reported, the factors are held to
+    the properties and to the approximation quality of LAPACK's own pivots (the exact-pivot set is the next test)."""
     from rusty_compression_amd import batch
 
     n, k = 4096, 64
@@ -735,15 +902,63 @@ def test_cfg5_rank64_column_id_4096_f32():
     assert is_permutation(indn, n)
     assert rel(cn, an[:, indn[:k]]) <= 1e-4                      # C = A[:, col_ind[:k]]
     assert rel(zn[:, indn[:k]], np.eye(k)) <= 1e-5               # Z restricted to the chosen columns is the identity
-    # the same factors as the (truncated) oracle: pivots under the f32 near-tie rule, then C Z
     oq, orr, oind = o.pivoted_qr(an)                             # full sgeqp3 + sorgqr, ~4 s
     gq, gr, gi = (npy(t) for t in rc.pivoted_qr(a, rank=k))
-    ns = agreed_pivot_prefix(gi, gr, oind, orr, np.float32)
-    assert ns >= 3
+    ns = agreed_pivot_prefix(gi, gr, oind, orr, np.float32)      # asserts that the first disagreement is a near tie
+    print(f"cfg5 Gaussian: agreed pivot prefix {ns} of {k}")
+    assert ns >= 1 and gi[0] == oind[0]
     ocid = o.QR(oq, orr, oind).compress("RANK", k).column_id()
     err_ours = np.linalg.norm(an - cn @ zn) / np.linalg.norm(an)
     err_ref = np.linalg.norm(an - ocid.c @ ocid.z) / np.linalg.norm(an)
     assert abs(err_ours - err_ref) <= 2e-3 * err_ref             # same approximation quality as LAPACK's pivots
+
+
+def test_cfg5_decaying_spectrum_set_has_sgeqp3_pivots_exactly():
+    """SURVEY.md 8(d), second cfg5 set: 4096 x 4096 f32 built by the decaying-spectrum recipe, so that the pivots are
+    determined by the data: ALL 64 pivots equal sgeqp3's (a disagreement is accepted only where
+    helpers.agreed_pivot_prefix proves a near tie), C = A[:, ind[:k]] and C, Z, C Z against the oracle's to 1e-4."""
+    from rusty_compression_amd import batch
+
+    n, k = 4096, 64
+    a = _decaying_matrix(n, 1e-5, torch.float32, 5)
+    an = npy(a)
+    c, z, ind = batch.column_id_rank(a, k)
+    cn, zn, indn = npy(c), npy(z), npy(ind)
+    assert is_permutation(indn, n)
+    oq, orr, oind = o.pivoted_qr(an)
+    gq, gr, gi = (npy(t) for t in rc.pivoted_qr(a, rank=k))
+    assert np.array_equal(gi, indn)                              # the ID reports the factorization's permutation
+    ns = agreed_pivot_prefix(gi[:k], gr, oind[:k], orr[:k], np.float32)
+    assert ns == k, f"only {ns} of {k} pivots agree with sgeqp3"
+    assert rel(gr[:, indn.argsort()], orr[:k][:, oind.argsort()]) <= 1e-4   # R rows in original column order
+    assert rel(gq, oq[:, :k]) <= 1e-4
+    ocid = o.QR(oq, orr, oind).compress("RANK", k).column_id()
+    assert rel(cn, an[:, oind[:k]]) <= 1e-5 and rel(cn, ocid.c) <= 1e-4
+    assert rel(zn, ocid.z) <= 1e-4
+    assert rel(cn @ zn, ocid.c @ ocid.z) <= 1e-4
+
+
+def test_cfg5_batch_of_eight_on_one_gpu_packs_and_unpacks_exactly():
+    """configs[4] per-GPU shard: 8 matrices through batch.batch_column_id on device tensors (rc_batch_column_id_f32 behind
+    it), results identical to one-by-one calls, pack -> unpack round trip exact (the buffer the RCCL gather moves)."""
+    from rusty_compression_amd import batch
+
+    n, k = 4096, 64
+    mats = [rc.random_gaussian((n, n), rc.Rng(500 + i), torch.float32) for i in range(8)]
+    out = batch.batch_column_id(mats, k)
+    assert len(out) == 8
+    for i in (0, 3, 7):
+        c1, z1, i1 = batch.column_id_rank(mats[i], k)
+        assert torch.equal(out[i][2], i1) and torch.equal(out[i][0], c1) and torch.equal(out[i][1], z1)
+    for (c, z, ind), a in zip(out, mats):
+        indn = npy(ind)
+        assert is_permutation(indn, n)
+        assert rel(npy(c), npy(a[:, ind[:k]])) <= 1e-4              # C = Q R11 reproduces the selected columns
+    packed = batch.pack_factors(out)
+    assert packed.is_cuda and packed.numel() * packed.element_size() == 8 * batch.packed_bytes(n, n, k, 4)
+    back = batch.unpack_factors(packed, 8, n, n, k)
+    for (c, z, ind), (c2, z2, ind2) in zip(out, back):
+        assert torch.equal(c, c2) and torch.equal(z, z2) and torch.equal(ind, ind2)
 
 
 # ---------------------------------------------------------------- short-wide pivoted QR: cooperative / lazy / eager
