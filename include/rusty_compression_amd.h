@@ -131,7 +131,13 @@ rc_status rc_graph_destroy(rc_context *ctx, void *graph_exec);
  * the pivoted-QR / ID branch) side by side on a second stream owned by the context (fork / join with events; captured
  * into the same hipGraph).  Latency of one compression 6.8 -> 5.6 ms; with dozens of such graphs in flight the
  * throughput measured lower (680 vs 913 compressions/s), hence opt-in. */
-enum { RC_OPT_TALL_SKINNY_FAST_PATH = 1, RC_OPT_WIDE_LAZY_QRCP = 2, RC_OPT_WIDE_COOP_QRCP = 3, RC_OPT_POWER_ITERATION_FIXED = 4, RC_OPT_FORK_BRANCHES = 5 };
+/* RC_OPT_BLOCKED_QRCP (default 1): pivoted QR of general shapes (neither tall-skinny nor short-wide) runs ?geqp3 the way
+ * LAPACK does -- ?laqps panels of 32 steps with the delayed F-matrix update and one MFMA GEMM block update per panel -- with
+ * the panel restricted to the candidate columns whose norm can still be the maximum (kernels_qrblk.hip): identical pivoting
+ * rule and down-dating formulas, about three passes over the trailing matrix per panel instead of two per step.  Reads one
+ * small struct back per panel, so it is not used while a hipGraph is being captured.  0 selects the per-step chain. */
+enum { RC_OPT_TALL_SKINNY_FAST_PATH = 1, RC_OPT_WIDE_LAZY_QRCP = 2, RC_OPT_WIDE_COOP_QRCP = 3, RC_OPT_POWER_ITERATION_FIXED = 4, RC_OPT_FORK_BRANCHES = 5,
+       RC_OPT_BLOCKED_QRCP = 6 };
 rc_status rc_set_option(rc_context *ctx, int32_t option, int64_t value);
 /* Health word (read and cleared), OR of: 1 non-positive Cholesky pivot, 2 first CholeskyQR pass too far from orthonormal
  * (both: tall-skinny fast path inside a graph, where no fallback is possible), 4 cooperative short-wide QR could not get

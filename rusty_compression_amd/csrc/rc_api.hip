@@ -274,8 +274,12 @@ void qrcp_core(rc_context *c, Mat<T> w, int64_t k, bool pivot, Mat<T> q, Mat<T> 
         return;
     }
     T *tau = c->alloc<T>((size_t)std::max<int64_t>(k, 1));
-    T *vn = c->alloc<T>((size_t)std::max<int64_t>(2 * n, 1));
-    geqp3_inplace(c, w, k, pivot, ind, tau, vn);
+    if (c->opt_blocked && pivot && !c->capturing && geqp3_blocked_supported<T>(w.rows, n, k)) {
+        geqp3_blocked<T>(c, w, k, ind, tau);
+    } else {
+        T *vn = c->alloc<T>((size_t)std::max<int64_t>(2 * n, 1));
+        geqp3_inplace(c, w, k, pivot, ind, tau, vn);
+    }
     if (!r.empty()) extract_r(c, w, ind, r);
     if (!q.empty()) {
         if (q.rs == 1 && q.cs >= q.rows) {
@@ -914,6 +918,7 @@ rc_status rc_set_option(rc_context *ctx, int32_t option, int64_t value) {
         case RC_OPT_WIDE_COOP_QRCP: ctx->opt_wide_coop = value != 0; return RC_OK;
         case RC_OPT_POWER_ITERATION_FIXED: ctx->opt_power_fixed = value != 0; return RC_OK;
         case RC_OPT_FORK_BRANCHES: ctx->opt_fork = value != 0; return RC_OK;
+        case RC_OPT_BLOCKED_QRCP: ctx->opt_blocked = value != 0; return RC_OK;
         default: ctx->last_error = "unknown option"; return RC_INVALID_ARGUMENT;
     }
 }

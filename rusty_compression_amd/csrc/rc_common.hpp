@@ -120,6 +120,7 @@ struct rc_context {
     int opt_power_fixed = 0;  // 1: sample_range_power_iteration really iterates it_count times (opt-in; the reference does one)
     int opt_wide_coop = 1;  // short-wide pivoted QR as ONE cooperative register-resident kernel (0: multi-kernel paths)
     int opt_wide_lazy = 1;  // short-wide pivoted QR through the read-only lazy scheme (0: eager Householder chain)
+    int opt_blocked = 1;    // general shapes: blocked ?laqps panels + GEMM block update (0: per-step Householder chain)
     int *health = nullptr;
     int *health_word();
     unsigned *epoch = nullptr;  // launch counter of the fused Jacobi (keys its producer -> consumer records)
@@ -208,6 +209,10 @@ template <typename T> void gemm(rc_context *c, T alpha, Mat<T> a, Mat<T> b, T be
 //   tau    : kmax
 //   vn     : 2n scratch (partial norms)
 template <typename T> void geqp3_inplace(rc_context *c, Mat<T> w, int64_t kmax, bool pivot, int64_t *jpvt, T *tau, T *vn);
+// general shapes (kernels_qrblk.hip): ?laqps panels on a candidate set + one MFMA GEMM block update per panel; same output
+// format as geqp3_inplace; reads one small struct back per panel (not capturable in a hipGraph)
+template <typename T> bool geqp3_blocked_supported(int64_t m, int64_t n, int64_t kmax);
+template <typename T> void geqp3_blocked(rc_context *c, Mat<T> w, int64_t kmax, int64_t *jpvt, T *tau);
 // short-wide matrices (m <= 256 << n): read-only "lazy" pivoted QR with the explicit m x m factor
 template <typename T> bool wide_lazy_supported(int64_t m, int64_t n);
 template <typename T> void geqp3_wide_lazy(rc_context *c, Mat<T> b, int64_t kmax, int64_t *jpvt, Mat<T> q, Mat<T> r);

@@ -878,6 +878,83 @@ def test_cfg4_adaptive_two_sided_id_16384x4096():
     assert np.linalg.norm(npy(ts.x) - sub) <= 1e-5 * np.linalg.norm(npy(a))
 
 
+def _with_blocked(on, fn):
+    from rusty_compression_amd import _lib
+
+    ctx = _lib.default_context()
+    ctx.set_option(_lib.RC_OPT_BLOCKED_QRCP, 1 if on else 0)
+    try:
+        return fn()
+    finally:
+        ctx.set_option(_lib.RC_OPT_BLOCKED_QRCP, 1)
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+@pytest.mark.parametrize("shape,smin,rank", [((300, 300), 1e-6, None), ((1000, 777), 1e-8, None), ((700, 1500), 1e-5, None), ((2048, 2048), 1e-6, 96),
+                                              ((1500, 1100), 1e-3, 70), ((640, 4000), 1e-4, 33), ((513, 259), 1e-9, None)])
+def test_blocked_qrcp_matches_lapack_and_the_per_step_chain(dtype, shape, smin, rank):
+    """General shapes through the blocked ?laqps path (kernels_qrblk.hip: candidate-set panels, GEMM block update) against
+    ?geqp3 + ?orgqr (pivots bit-exact on the prefix the data determines, near-tie rule at a first disagreement, factors to
+    tolerance) and against the library's own per-step chain (RC_OPT_BLOCKED_QRCP = 0), full and truncated."""
+    f64 = dtype == np.float64
+    tol = TOL[np.dtype(dtype)]
+    rng = np.random.default_rng(shape[0] + shape[1])
+    a = o.random_approximate_low_rank_matrix(shape, 1.0, smin if f64 else max(smin, 1e-4), rng, dtype)
+    k = rank or min(shape)
+    oq, orr, oind = o.pivoted_qr(a)
+    res = {}
+    for blocked in (True, False):
+        q, r, ind = _with_blocked(blocked, lambda: tuple(npy(t) for t in rc.pivoted_qr(a, rank=k)))
+        assert is_permutation(ind, shape[1])
+        ns = agreed_pivot_prefix(ind[:k], r, oind[:k], orr[:k], dtype)
+        want = min(k, stable_prefix(orr, dtype))
+        # f64: every pivot the data determines; f32: a first disagreement may be a proven near tie (agreed_pivot_prefix asserts it)
+        assert (ns == want) if f64 else (ns >= want // 4), f"blocked={blocked}: {ns} of {want} pivots agree with ?geqp3"
+        assert np.abs(q.T @ q - np.eye(k)).max() <= (1e-12 if f64 else 2e-5)
+        assert rel(q @ r, a[:, ind]) <= (tol["recon"] * 10 if rank is None else 1.0)  # truncated: not a full factorization
+        ia = ind.argsort()
+        assert rel(r[:ns][:, ia], orr[:ns][:, oind.argsort()]) <= tol["factor"] * (1 if f64 else 3)
+        # columns of Q that belong to tiny |r_jj| are ill-determined (sensitivity ~ eps |r_00| / |r_jj|): compare the leading ones
+        lead = min(ns, int((np.abs(np.diag(orr)) > np.abs(orr[0, 0]) * (1e-4 if f64 else 1e-2)).sum()))
+        assert rel(q[:, :lead], oq[:, :lead]) <= tol["factor"] * (10 if f64 else 3)
+        res[blocked] = (q, r, ind)
+    nsb = agreed_pivot_prefix(res[True][2][:k], res[True][1], res[False][2][:k], res[False][1], dtype)
+    assert nsb >= (min(k, stable_prefix(orr, dtype)) if f64 else 1)
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_blocked_qrcp_degenerate_inputs(dtype):
+    """All-equal norms (every column a candidate: plain ?laqps), exact ties (first position wins), zero and rank-deficient
+    matrices, a panel that must end early because a norm loses its accuracy."""
+    f64 = dtype == np.float64
+    n = 256
+    # identity-like: all norms tie -> LAPACK takes positions in order
+    e = np.eye(n, dtype=dtype)
+    q, r, ind = (npy(t) for t in rc.pivoted_qr(e))
+    oq, orr, oind = o.pivoted_qr(e)
+    assert np.array_equal(ind, oind) and rel(r, orr) <= 1e-6
+    # duplicated columns: the first of each tie is taken
+    rng = np.random.default_rng(12)
+    b = rng.standard_normal((300, 160)).astype(dtype)
+    b[:, 80:] = b[:, :80]
+    q, r, ind = (npy(t) for t in rc.pivoted_qr(b))
+    oq, orr, oind = o.pivoted_qr(b)
+    ns = stable_prefix(orr, dtype)
+    assert ns <= 90 and np.array_equal(ind[:ns], oind[:ns])
+    assert rel(q @ r, b[:, ind]) <= (1e-12 if f64 else 1e-5)
+    # zero matrix
+    z = np.zeros((200, 300), dtype=dtype)
+    q, r, ind = (npy(t) for t in rc.pivoted_qr(z))
+    assert np.array_equal(ind, np.arange(300)) and np.all(r == 0) and np.array_equal(q, np.eye(200, dtype=dtype))
+    # exact rank 40 inside 400 x 400: after 40 steps every norm collapses (tol3z recomputations galore)
+    x = (rng.standard_normal((400, 40)) @ rng.standard_normal((40, 400))).astype(dtype)
+    q, r, ind = (npy(t) for t in rc.pivoted_qr(x))
+    oq, orr, oind = o.pivoted_qr(x)
+    ns = stable_prefix(orr, dtype)
+    assert 38 <= ns <= 42 and np.array_equal(ind[:ns], oind[:ns])
+    assert rel(q @ r, x[:, ind]) <= (1e-12 if f64 else 2e-5) and np.abs(q.T @ q - np.eye(400)).max() <= (1e-12 if f64 else 2e-5)
+
+
 def _decaying_matrix(n, sigma_min, dtype, seed):
     """The reference's test-matrix recipe (src/random_matrix.rs:70-93) at full size: A = U diag(geomspace(sigma_min, 1)) V^T with
     U, V the orthogonal factors of seeded Gaussians.  Input generation only: the factors come from torch's QR."""
