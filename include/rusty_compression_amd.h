@@ -326,6 +326,37 @@ rc_status rc_rsvd_id_f32(rc_context *ctx, rc_matrix a, int64_t k, int64_t p, rc_
 rc_status rc_column_id_rank_f64(rc_context *ctx, rc_matrix a, int64_t k, rc_matrix c, rc_matrix z, int64_t *col_ind);
 rc_status rc_column_id_rank_f32(rc_context *ctx, rc_matrix a, int64_t k, rc_matrix c, rc_matrix z, int64_t *col_ind);
 
+/* ------------------------------------------- batches of independent matrices -- */
+/* BASELINE.json configs[4]: many same-shaped matrices, rank-k column ID each (the call sequence of
+ * examples/interpolative_decomposition.rs:25-32 per matrix), sharded by MATRIX over the GPUs of a node, then ONE exchange
+ * step: the gather of the finished factor blocks.  The reference has neither a batch nor a communication layer (it is
+ * single-process host code), so these entry points have no file:line counterpart beyond the per-matrix sequence.
+ *
+ * Packed layout, per matrix i at byte offset i * rc_batch_packed_bytes(m, n, k, sizeof(T)):
+ *   C (m x k, C order) | Z (k x n, C order) | pad to 8 bytes | col_ind (n x int64). */
+size_t rc_batch_packed_bytes(int64_t m, int64_t n, int64_t k, int32_t elem_size);
+/* Contiguous block partition of n_items over `world` ranks (the first n_items % world ranks take one extra item):
+ * matrix i of 64 goes to rank i / 8 on 8 GPUs.  Pure host arithmetic. */
+rc_status rc_batch_shard_range(int64_t n_items, int32_t world, int32_t rank, int64_t *start, int64_t *count);
+/* Rank-k column ID of `count` same-shaped device matrices into the packed device buffer `packed`
+ * (count * rc_batch_packed_bytes).  The matrices are spread over the nctx contexts (one HIP stream each, same device) and
+ * advanced in lock step, one host wait per pivoting panel for ALL of them; results are identical to count calls of
+ * rc_column_id_rank_*.  Blocking: returns when every factor is in `packed`.  Errors are reported on ctxs[0]. */
+rc_status rc_batch_column_id_f64(rc_context *const *ctxs, int32_t nctx, const rc_matrix *mats, int32_t count, int64_t k, void *packed);
+rc_status rc_batch_column_id_f32(rc_context *const *ctxs, int32_t nctx, const rc_matrix *mats, int32_t count, int64_t k, void *packed);
+
+/* The gather over RCCL (xGMI inside a node).  One process per GPU: rank 0 calls rc_comm_unique_id and hands the 128
+ * bytes to the other ranks by whatever means the host has (MPI, a file, torch.distributed), every rank calls
+ * rc_comm_init, then rc_comm_gather moves bytes_per_rank bytes from every rank's `send` into
+ * recv[rank * bytes_per_rank ...] on `root` (grouped ncclSend / ncclRecv on the context's stream, asynchronous:
+ * rc_synchronize(ctx) completes it).  librccl is opened at run time; RC_RUNTIME_ERROR if it is not available. */
+typedef struct rc_comm rc_comm;
+rc_status rc_comm_unique_id(void *id128);
+rc_status rc_comm_init(rc_comm **comm, int32_t world, int32_t rank, const void *id128, int32_t device);
+rc_status rc_comm_gather(rc_comm *comm, rc_context *ctx, const void *send, void *recv, size_t bytes_per_rank, int32_t root);
+rc_status rc_comm_destroy(rc_comm *comm);
+const char *rc_comm_last_error_message(const rc_comm *comm);
+
 #ifdef __cplusplus
 }
 #endif

@@ -51,12 +51,14 @@ template <typename T> struct NumB;
 template <> struct NumB<double> {
     typedef unsigned long long key_t;
     static constexpr int kKeyBits = 64;
+    static constexpr int kSelBits = 32;
     static __host__ __device__ inline double tol3z() { return 1.0536712127723509e-08; }  // sqrt(2^-53)
     static __device__ inline key_t key(double v) { return (key_t)__double_as_longlong(fabs(v)); }
 };
 template <> struct NumB<float> {
     typedef unsigned int key_t;
     static constexpr int kKeyBits = 32;
+    static constexpr int kSelBits = 24;
     static __host__ __device__ inline float tol3z() { return 2.44140625e-04f; }  // sqrt(2^-24)
     static __device__ inline key_t key(float v) { return __float_as_uint(fabsf(v)); }
 };
@@ -72,20 +74,6 @@ struct QrbState {
     int pad0, pad1;
     int piv[kNB];      // physical column of the panel's pivots
 };
-
-// threads of the serial per-step kernel: 8 waves (two per SIMD) may use 256 registers each, which the batched loads need
-constexpr int kPT = 512;
-template <typename T>
-__device__ inline T block_sum_pt(T v, T *sh16) {
-    v = wave_sum_dpp(v);
-    __syncthreads();
-    if ((threadIdx.x & 63) == 0) sh16[threadIdx.x >> 6] = v;
-    __syncthreads();
-    T s = 0;
-#pragma unroll
-    for (int i = 0; i < kPT / 64; ++i) s += sh16[i];
-    return s;
-}
 
 // ---------------------------------------------------------------------------
 // init: identity permutation, exact column norms (indexed by PHYSICAL column: columns never move)
@@ -114,7 +102,7 @@ __global__ __launch_bounds__(256) void k_qrb_init(Mat<T> w, int64_t *jpvt, int *
 // ---------------------------------------------------------------------------
 template <typename T>
 __global__ __launch_bounds__(1024) void k_qrb_select(int n, int j0, int cwant, const int *pos, const T *vn1, int *cand, unsigned char *is_cand,
-                                                     QrbState *st, T *tsc) {
+                                                     QrbState *st, T *tsc, int *cpos0, T *cvn0) {
     typedef typename NumB<T>::key_t key_t;
     __shared__ int hist[256];
     __shared__ int sh_scan[1024];
@@ -127,7 +115,9 @@ __global__ __launch_bounds__(1024) void k_qrb_select(int n, int j0, int cwant, c
     if (nu > cwant) {
         if (tid == 0) { sh_prefix = 0; sh_need = cwant; }
         key_t mask = 0;
-        for (int shift = NumB<T>::kKeyBits - 8; shift >= 0; shift -= 8) {
+        // the leading kSelBits bits of the norm decide (f32: sign + exponent + 15 mantissa bits, f64: + 20): the candidate
+        // set is "every norm >= the bin of the cwant-th largest", i.e. at least cwant columns, ties and near-ties included
+        for (int shift = NumB<T>::kKeyBits - 8; shift >= NumB<T>::kKeyBits - NumB<T>::kSelBits; shift -= 8) {
             if (tid < 256) hist[tid] = 0;
             __syncthreads();
             const key_t prefix = sh_prefix;
@@ -137,14 +127,32 @@ __global__ __launch_bounds__(1024) void k_qrb_select(int n, int j0, int cwant, c
                 if ((kx & mask) == prefix) atomicAdd(&hist[(int)((kx >> shift) & 255)], 1);
             }
             __syncthreads();
-            if (tid == 0) {
-                int need = sh_need, cum = 0, b = 255;
-                for (; b > 0; --b) {
-                    if (cum + hist[b] >= need) break;
-                    cum += hist[b];
+            // suffix counts S[b] = sum_{b' >= b} hist[b'] by the first 256 threads; the bin with S[b] >= need > S[b + 1] is chosen
+            if (tid < 256) {
+                const int lane = tid & 63, wv = tid >> 6;
+                int v = hist[tid];
+#pragma unroll
+                for (int off = 1; off < 64; off <<= 1) {
+                    const int o = __shfl_down(v, off, 64);
+                    if (lane + off < 64) v += o;
                 }
-                sh_need = need - cum;
-                sh_prefix = prefix | ((key_t)b << shift);
+                if (lane == 0) sh_scan[wv] = v;  // wave totals
+                sh_scan[8 + tid] = v;            // in-wave suffix sums
+            }
+            __syncthreads();
+            if (tid < 256) {
+                const int wv = tid >> 6;
+                int above = 0;
+                for (int w2 = wv + 1; w2 < 4; ++w2) above += sh_scan[w2];
+                const int sfx = sh_scan[8 + tid] + above;          // S[tid]
+                const int nextv = sfx - hist[tid];                   // S[tid + 1]
+                const int need = sh_need;
+                if (sfx >= need && nextv < need) { sh_scan[300] = tid; sh_scan[301] = need - nextv; }
+            }
+            __syncthreads();
+            if (tid == 0) {
+                sh_need = sh_scan[301];
+                sh_prefix = prefix | ((key_t)sh_scan[300] << shift);
             }
             mask |= (key_t)255 << shift;
             __syncthreads();
@@ -173,7 +181,7 @@ __global__ __launch_bounds__(1024) void k_qrb_select(int n, int j0, int cwant, c
     }
     int o = sh_scan[tid] - cnt;
     for (int c = c0; c < c1; ++c)
-        if (is_cand[c]) cand[o++] = c;
+        if (is_cand[c]) { cand[o] = c; cpos0[o] = pos[c]; cvn0[o] = vn1[c]; ++o; }
     tmax = wave_max_dpp(tmax);
     if ((tid & 63) == 0) sh_t[tid >> 6] = tmax;
     __syncthreads();
@@ -182,261 +190,445 @@ __global__ __launch_bounds__(1024) void k_qrb_select(int n, int j0, int cwant, c
         for (int i = 0; i < 16; ++i) t = max(t, sh_t[i]);
         const int nc = sh_scan[1023];
         tsc[0] = t;
-        st->stopped = 0; st->kb = 0; st->lsticc = 0; st->stop_tau = 0;
+        st->stopped = 0; st->kb = 0; st->lsticc = 0; st->stop_tau = 0; st->pad0 = 0;
         st->ncand = nc;
         st->have_noncand = nc < nu ? 1 : 0;
     }
 }
 
 // ---------------------------------------------------------------------------
-// step k, serial part (one workgroup): pivot among the candidates, stop tests, "swap", pivot column brought
-// up to date, ?larfg, auxv = -tau V^T v and column k of the panel's T factor.
+// Per-step kernels.  Both are multi-workgroup and free of serial single-CU passes; the few scalar decisions of a step
+// (pivot, stop tests, ?larfg) are evaluated REDUNDANTLY by every workgroup from the same inputs in the same order, so all
+// workgroups agree bit for bit, and only workgroup 0 writes the shared bookkeeping.  Data that one kernel both reads and
+// replaces is double buffered (candidate norms / positions) or kept out of place (the updated pivot column, the rows of
+// R of the candidates), so no workgroup can observe another one's writes of the same launch.
+//
+//   step A(k): finish step k-1 for every candidate (F(c, k-1), its entry of row rk-1 of R, norm down-date), pick the
+//              pivot of step k, stop tests, bring the pivot column up to date (row slabs over the workgroups)
+//   step C(k): ?larfg from the slab partial sums, dot products of v_k with every candidate and with the panel's earlier
+//              reflectors (one wave per column), v_k stored
+// A panel of nbp steps is A(0) C(0) ... A(nbp-1) C(nbp-1) A(nbp, final).
 // ---------------------------------------------------------------------------
 template <typename T>
-__global__ __launch_bounds__(kPT) void k_qrb_pivot(Mat<T> w, int j0, int k, int64_t *jpvt, int *pos, const T *vn1, const T *Fm, const int *cand,
-                                                    QrbState *st, const T *tsc, T *tau, T *auxv, T *Tm) {
-    __shared__ T sh16[16];
-    __shared__ int shp[16], shc[16];
-    __shared__ T shF[kNB];
-    __shared__ T shaux[kNB];
-    __shared__ int shpiv[kNB];
-    __shared__ const T *shcol[kNB];
-    __shared__ T shred[16 * kNB];
-    __shared__ int sh_go;
-    __shared__ T sh_alpha;
-    if (st->stopped) return;
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const int rk = j0 + k;
-    const int64_t m = w.rows;
-    if (st->lsticc) {  // ?laqps: the panel ends after the step in which a norm lost its accuracy
-        if (tid == 0) { st->stopped = 1; st->kb = k; }
-        return;
+struct QrbPanel {
+    int64_t *jpvt;
+    int *pos;             // n: position of physical column (workgroup 0 of step A is the only writer)
+    const int *cand;      // candidate -> physical column
+    int *cpos[2];         // candidate positions, double buffered by step parity
+    T *cvn[2];            // candidate partial norms (vn1), double buffered
+    const T *vn2;         // n: last exactly computed norm per physical column
+    T *Fm;                // n x kNB, row per physical column
+    T *G;                 // raw dot products of the current step, per candidate
+    T *gv;                // kNB: dot products with the panel's earlier reflectors
+    T *Rrow;              // kNB x ncap: row j0 + kk of R for the candidates (scattered into the matrix at panel end)
+    int64_t ncap;
+    T *xbuf;              // m: the pivot column brought up to date (rows rk .. m-1 at offset 0)
+    T *pss;               // per-slab partial sums of squares + [64] = alpha
+    int *flag;            // n: norm lost its accuracy, recompute after the block update
+    QrbState *st;
+    const T *tsc;         // [0] = tau threshold
+    T *tau;
+    T *auxv;              // kNB (kept for the panel-end kernels)
+    T *Tm;                // kNB x kNB
+};
+
+template <typename T>
+__device__ inline bool qrb_downdate(T a, T &vn, T vnb) {  // ?laqps norm down-date; true = accuracy lost (vn unchanged)
+    if (vn == (T)0) return false;
+    T temp = fabs(a) / vn;
+    temp = ((T)1 + temp) * ((T)1 - temp);
+    temp = temp > (T)0 ? temp : (T)0;
+    const T r = vn / vnb;
+    if (temp * r * r <= NumB<T>::tol3z()) return true;
+    vn *= sqrt(temp);
+    return false;
+}
+
+// F row of a candidate in registers (16-byte loads, all in flight together)
+template <typename T>
+struct QrbRow {
+    static constexpr int VL = 16 / sizeof(T);
+    typedef T vecT __attribute__((ext_vector_type(VL)));
+    vecT f[kNB / VL];
+    __device__ inline void load(const T *frow) {
+        const vecT *fv = reinterpret_cast<const vecT *>(frow);
+#pragma unroll
+        for (int q = 0; q < kNB / VL; ++q) f[q] = fv[q];
     }
-    // ---- pivot: largest norm, lowest position (idamax) over the unpivoted candidates ----------------------
+    // e = F(c, :) . aux, sr = vrow . F(c, :) over all 32 entries (entries beyond the current step meet zeros in aux / vrow;
+    // the F matrix is zero-initialised, so they are finite)
+    __device__ inline void dots(const T *aux, const T *vrow, T &e, T &sr) const {
+        e = 0;
+        sr = 0;
+#pragma unroll
+        for (int q = 0; q < kNB / VL; ++q)
+#pragma unroll
+            for (int u = 0; u < VL; ++u) {
+                e = fma(f[q][u], aux[q * VL + u], e);
+                sr = fma(vrow[q * VL + u], f[q][u], sr);
+            }
+    }
+    __device__ inline void store_lds(T *dst) const {
+#pragma unroll
+        for (int q = 0; q < kNB / VL; ++q)
+#pragma unroll
+            for (int u = 0; u < VL; ++u) dst[q * VL + u] = f[q][u];
+    }
+};
+
+// Step A.  The kernel is a chain of dependent global-memory round trips (~0.7 us each), so loads are grouped into three
+// rounds: (1) panel state + this thread's candidates, (2) their F rows / dot products / matrix entries, (3) the pivot
+// column slab with all of the panel's reflector rows.
+template <typename T>
+__global__ __launch_bounds__(256) void k_qrb_step_a(Mat<T> w, int j0, int k, int final_only, QrbPanel<T> P) {
+    __shared__ T shaux[kNB], shvrow[kNB], shF[kNB];
+    __shared__ int shpiv[kNB];
+    __shared__ T shv[4];
+    __shared__ int shp[4], shi[4], shc[4], shlost[4];
+    __shared__ T sh4[4];
+    QrbState *st = P.st;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const bool wg0 = blockIdx.x == 0;
+    const int rk = j0 + k, rkp = rk - 1;
+    const int cur = k & 1, nxt = cur ^ 1;
+    const int64_t m = w.rows;
+    const int kp = k - 1;  // the step being finished
+    const int *cposc = P.cpos[cur];
+    const T *cvnc = P.cvn[cur];
+    // ---- round 1 ----------------------------------------------------------------------------------------------------
+    constexpr int NPF = 2;  // candidates per thread fetched ahead (512 per workgroup); further ones are fetched in the loop
+    int pf_p[NPF], pf_c[NPF];
+    T pf_vn[NPF];
+#pragma unroll
+    for (int e = 0; e < NPF; ++e) {
+        const int ci = tid + 256 * e;
+        const bool ok = ci < (int)P.ncap;
+        pf_p[e] = ok ? cposc[ci] : -1;
+        pf_vn[e] = ok ? cvnc[ci] : (T)0;
+        pf_c[e] = ok ? P.cand[ci] : 0;
+    }
+    const int stopped = st->stopped;
     const int ncand = st->ncand;
+    const int have_noncand = st->have_noncand;
+    const T lim = P.tsc[0] * ((T)1 + (T)4 * NumB<T>::tol3z());
+    const T tkp = k > 0 ? P.tau[rkp] : (T)0;
+    int mypiv = 0;
+    T mygv = 0;
+    if (tid < kNB && k > 0) {
+        mypiv = st->piv[tid < k ? tid : 0];
+        mygv = tid < kp ? P.gv[tid] : (T)0;
+    }
+    if (stopped) return;
+    // ---- round 2: F rows and the per-candidate scalars; reflector entries of row rk-1 ------------------------------------
+    QrbRow<T> row[NPF];
+    T pf_g[NPF], pf_w[NPF], pf_v2[NPF];
+    bool act[NPF];
+#pragma unroll
+    for (int e = 0; e < NPF; ++e) {
+        const int ci = tid + 256 * e;
+        act[e] = k > 0 && ci < ncand && pf_p[e] > rkp;  // unpivoted while step k-1 ran
+        pf_g[e] = pf_w[e] = pf_v2[e] = 0;
+        if (act[e]) {
+            row[e].load(P.Fm + (int64_t)pf_c[e] * kNB);
+            pf_g[e] = P.G[ci];
+            pf_w[e] = w.p[(int64_t)pf_c[e] * w.cs + rkp];
+            pf_v2[e] = P.vn2[pf_c[e]];
+        }
+    }
+    T trow[kNB];  // workgroup 0, thread r < k-1: row r of the panel's T factor (columns r .. k-2)
+#pragma unroll
+    for (int q = 0; q < kNB; ++q) trow[q] = (wg0 && tid < kp && q >= tid && q < kp) ? P.Tm[tid + q * kNB] : (T)0;
+    if (tid < kNB) {
+        shpiv[tid] = mypiv;
+        shaux[tid] = tid < kp ? -tkp * mygv : (T)0;
+        shvrow[tid] = (k > 0 && tid < kp) ? w.p[(int64_t)mypiv * w.cs + rkp] : (T)0;
+    }
+    __syncthreads();
+    // ---- finish step k-1 for every candidate + arg max for step k ------------------------------------------------------
     T best = (T)-1;
-    int bp = 0x7fffffff, bc = -1;
-    for (int i = tid; i < ncand; i += kPT) {
-        const int c = cand[i];
-        const int p = pos[c];
-        if (p < rk) continue;
-        const T v = fabs(vn1[c]);
-        if (v > best || (v == best && p < bp)) { best = v; bp = p; bc = c; }
+    int bp = 0x7fffffff, bi = -1, bcol = 0, lost_any = 0;
+    T my_fk[NPF];
+#pragma unroll
+    for (int e = 0; e < NPF; ++e) {
+        const int ci = tid + 256 * e;
+        my_fk[e] = 0;
+        if (ci < ncand) {
+            T vn = pf_vn[e];
+            if (act[e]) {
+                T ee, sr;
+                row[e].dots(shaux, shvrow, ee, sr);
+                const T fk = tkp * pf_g[e] + ee;
+                my_fk[e] = fk;
+                const T a = pf_w[e] - (sr + fk);
+                const bool lost = qrb_downdate(a, vn, pf_v2[e]);
+                if (lost) lost_any = 1;
+                if (wg0) {
+                    P.Fm[(int64_t)pf_c[e] * kNB + kp] = fk;
+                    P.Rrow[(int64_t)kp * P.ncap + ci] = a;
+                    if (lost) P.flag[pf_c[e]] = 1;
+                }
+            }
+            if (wg0) P.cvn[nxt][ci] = vn;
+            if (pf_p[e] >= rk) {
+                const T v = fabs(vn);
+                if (v > best || (v == best && pf_p[e] < bp)) { best = v; bp = pf_p[e]; bi = ci; bcol = pf_c[e]; }
+            }
+        }
+    }
+    for (int ci = tid + 256 * NPF; ci < ncand; ci += 256) {  // more than 512 candidates: the same, fetched on the spot
+        const int p = cposc[ci];
+        const int c = P.cand[ci];
+        T vn = cvnc[ci];
+        if (k > 0 && p > rkp) {
+            QrbRow<T> r2;
+            r2.load(P.Fm + (int64_t)c * kNB);
+            T ee, sr;
+            r2.dots(shaux, shvrow, ee, sr);
+            const T fk = tkp * P.G[ci] + ee;
+            const T a = w.p[(int64_t)c * w.cs + rkp] - (sr + fk);
+            const bool lost = qrb_downdate(a, vn, P.vn2[c]);
+            if (lost) lost_any = 1;
+            if (wg0) {
+                P.Fm[(int64_t)c * kNB + kp] = fk;
+                P.Rrow[(int64_t)kp * P.ncap + ci] = a;
+                if (lost) P.flag[c] = 1;
+            }
+        }
+        if (wg0) P.cvn[nxt][ci] = vn;
+        if (p >= rk) {
+            const T v = fabs(vn);
+            if (v > best || (v == best && p < bp)) { best = v; bp = p; bi = ci; bcol = c; }
+        }
     }
     {
         const T mx = wave_max_dpp(best);
-        int pc = (best == mx && bc >= 0) ? bp : 0x7fffffff;
+        int pc = (best == mx && bi >= 0) ? bp : 0x7fffffff;
         pc = wave_min_dpp(pc);
-        if (bc >= 0 && best == mx && bp == pc) { sh16[wv] = mx; shp[wv] = bp; shc[wv] = bc; }
-        else if (lane == 0 && pc == 0x7fffffff) { sh16[wv] = (T)-1; shp[wv] = 0x7fffffff; shc[wv] = -1; }
+        if (bi >= 0 && best == mx && bp == pc) { shv[wv] = mx; shp[wv] = bp; shi[wv] = bi; shc[wv] = bcol; }
+        else if (lane == 0 && pc == 0x7fffffff) { shv[wv] = (T)-1; shp[wv] = 0x7fffffff; shi[wv] = -1; shc[wv] = 0; }
+        int la = lost_any;
+        la |= __shfl_xor(la, 32, 64); la |= __shfl_xor(la, 16, 64); la |= __shfl_xor(la, 8, 64);
+        la |= __shfl_xor(la, 4, 64); la |= __shfl_xor(la, 2, 64); la |= __shfl_xor(la, 1, 64);
+        if (lane == 0) shlost[wv] = la;
     }
     __syncthreads();
-    if (tid == 0) {
-        T bb = sh16[0];
-        int pp = shp[0], cc = shc[0];
-        for (int i = 1; i < kPT / 64; ++i)
-            if (shc[i] >= 0 && (cc < 0 || sh16[i] > bb || (sh16[i] == bb && shp[i] < pp))) { bb = sh16[i]; pp = shp[i]; cc = shc[i]; }
-        int go = 1;
-        if (cc < 0) { st->stopped = 1; st->kb = k; go = 0; }  // every candidate has been used
-        else if (k > 0 && st->have_noncand) {
-            // a column outside the candidate set may be the true maximum once the best candidate is no longer
-            // above every excluded norm (margin: the accuracy LAPACK keeps its down-dated norms to)
-            const T lim = tsc[0] * ((T)1 + (T)4 * NumB<T>::tol3z());
-            if (!(bb > lim)) { st->stopped = 1; st->kb = k; st->stop_tau = 1; go = 0; }
+    T bb = shv[0];
+    int pp = shp[0], ci_s = shi[0], cs = shc[0];
+    for (int i = 1; i < 4; ++i)
+        if (shi[i] >= 0 && (ci_s < 0 || shv[i] > bb || (shv[i] == bb && shp[i] < pp))) { bb = shv[i]; pp = shp[i]; ci_s = shi[i]; cs = shc[i]; }
+    const int lost_all = shlost[0] | shlost[1] | shlost[2] | shlost[3];
+    // ---- workgroup 0: T column of step k-1, latest norm buffer -------------------------------------------------------
+    if (wg0 && k > 0) {
+        if (tid < kp) P.auxv[tid] = shaux[tid];
+        if (tid <= kp) {
+            T sacc = tkp;
+            if (tid < kp) {
+                sacc = 0;
+#pragma unroll
+                for (int q = 0; q < kNB; ++q) sacc = fma(trow[q], shaux[q], sacc);  // zeros outside tid <= q < k-1
+            }
+            P.Tm[tid + kp * kNB] = sacc;
         }
-        if (go) {
-            const int cold = (int)jpvt[rk];
+    }
+    if (wg0 && tid == 0) st->pad0 = nxt;  // buffer that holds the norms after step k-1
+    // ---- stop tests (identical in every workgroup) -----------------------------------------------------------------------
+    int stop = 0, why_tau = 0;
+    if (final_only) stop = 1;
+    else if (lost_all) stop = 1;                    // ?laqps: the panel ends after the step in which a norm lost its accuracy
+    else if (ci_s < 0) stop = 1;                    // every candidate has been used
+    else if (k > 0 && have_noncand && !(bb > lim)) { stop = 1; why_tau = 1; }
+    if (stop) {
+        if (wg0 && tid == 0) { st->stopped = 1; st->kb = k; st->lsticc = lost_all; st->stop_tau = why_tau; }
+        return;
+    }
+    // ---- workgroup 0: swap bookkeeping ------------------------------------------------------------------------------------
+    if (wg0) {
+#pragma unroll
+        for (int e = 0; e < NPF; ++e) {
+            const int ci = tid + 256 * e;
+            if (ci < ncand) P.cpos[nxt][ci] = ci == ci_s ? rk : (pf_p[e] == rk ? pp : pf_p[e]);
+        }
+        for (int ci = tid + 256 * NPF; ci < ncand; ci += 256) {
+            const int p = cposc[ci];
+            P.cpos[nxt][ci] = ci == ci_s ? rk : (p == rk ? pp : p);
+        }
+        if (tid == 0) {
+            const int cold = (int)P.jpvt[rk];
             if (pp != rk) {
-                jpvt[rk] = cc; jpvt[pp] = cold;
-                pos[cc] = rk; pos[cold] = pp;
+                P.jpvt[rk] = cs; P.jpvt[pp] = cold;
+                P.pos[cs] = rk; P.pos[cold] = pp;
             }
-            st->piv[k] = cc;
-            shpiv[k] = cc;
+            st->piv[k] = cs;
         }
-        sh_go = go;
     }
-    if (tid < k) shpiv[tid] = st->piv[tid];
+    // ---- F row of the pivot column: its owner thread has it in registers ------------------------------------------------------
+    if (tid < kNB) shF[tid] = 0;
     __syncthreads();
-    if (!sh_go) return;
-    const int c = shpiv[k];
-    // F row of the pivot column and the panel's reflector columns, padded to a multiple of the unroll width with F = 0 and
-    // a valid column, so that the inner loops carry no predicates and keep RB x 8 independent loads in flight
-    if (tid < kNB) {
-        shF[tid] = tid < k ? Fm[(int64_t)c * kNB + tid] : (T)0;
-        shcol[tid] = w.p + (int64_t)shpiv[tid < k ? tid : 0] * w.cs;
+    if (k > 0) {
+        if (ci_s < 256 * NPF) {
+#pragma unroll
+            for (int e = 0; e < NPF; ++e)
+                if (tid + 256 * e == ci_s) { row[e].store_lds(shF); shF[kp] = my_fk[e]; }
+        } else if (tid == 0) {
+            QrbRow<T> r2;
+            r2.load(P.Fm + (int64_t)cs * kNB);
+            T ee, sr;
+            r2.dots(shaux, shvrow, ee, sr);
+            r2.store_lds(shF);
+            shF[kp] = tkp * P.G[ci_s] + ee;
+        }
     }
     __syncthreads();
-    // ---- pivot column up to date: x = A(rk:m, c) - V(rk:m, 0:k) F(c, 0:k)^T ------------------------------
-    T *wc = w.p + (int64_t)c * w.cs;
-    constexpr int RB = 4, TB = 8;  // rows per thread and reflectors per batch of loads
-    const int kpad = (k + TB - 1) / TB * TB;
+    // ---- round 3: pivot column up to date, one row slab per workgroup: x = A(rk:m, c) - V(rk:m, 0:k) F(c, 0:k)^T -----------
+    const int64_t nrows = m - rk;
+    const int64_t slab = (nrows + gridDim.x - 1) / gridDim.x;
+    const int64_t r0 = (int64_t)blockIdx.x * slab, r1 = min(nrows, r0 + slab);
+    const T *wc = w.p + (int64_t)cs * w.cs + rk;
+    const int xoff = rk & (16 / (int)sizeof(T) - 1);  // xbuf(r) sits at the same 16-byte phase as row rk + r of a column
     T ss = 0;
-    for (int64_t ib = rk + tid; ib < m; ib += kPT * RB) {
-        T x[RB];
-        int64_t ii[RB];
+    for (int64_t r = r0 + tid; r < r1; r += 256) {
+        T x = wc[r];
+        T vv[kNB];
 #pragma unroll
-        for (int e = 0; e < RB; ++e) {
-            const int64_t i = ib + kPT * e;
-            ii[e] = i < m ? i : (int64_t)rk;  // out-of-range rows read row rk and are not written back
-            x[e] = wc[ii[e]];
-        }
-        for (int t0 = 0; t0 < kpad; t0 += TB) {
-            T vv[RB][TB];
+        for (int t = 0; t < kNB; ++t) vv[t] = t < k ? w.p[(int64_t)shpiv[t] * w.cs + rk + r] : (T)0;
 #pragma unroll
-            for (int u = 0; u < TB; ++u) {
-                const T *cp = shcol[t0 + u];
-#pragma unroll
-                for (int e = 0; e < RB; ++e) vv[e][u] = cp[ii[e]];
-            }
-#pragma unroll
-            for (int u = 0; u < TB; ++u) {
-                const T fu = shF[t0 + u];
-#pragma unroll
-                for (int e = 0; e < RB; ++e) x[e] = fma(-vv[e][u], fu, x[e]);
-            }
-        }
-#pragma unroll
-        for (int e = 0; e < RB; ++e) {
-            const int64_t i = ib + kPT * e;
-            if (i < m) {
-                wc[i] = x[e];
-                if (i > rk) ss = fma(x[e], x[e], ss);
-                else sh_alpha = x[e];
-            }
-        }
+        for (int t = 0; t < kNB; ++t) x = fma(-vv[t], shF[t], x);  // shF is zero beyond the step (and vv too)
+        P.xbuf[xoff + r] = x;
+        if (r > 0) ss = fma(x, x, ss);
+        else P.pss[64] = x;  // alpha
     }
-    ss = block_sum_pt(ss, sh16);  // (its barriers also publish sh_alpha)
-    // ---- ?larfg ----------------------------------------------------------------------------------------
-    const T alpha = sh_alpha;
-    const T xnorm = sqrt(ss);
-    T tk = 0, beta = alpha, scal = 0;
-    if (xnorm != (T)0) {
-        beta = -copysign(hypot(alpha, xnorm), alpha);
-        tk = (beta - alpha) / beta;
-        scal = (T)1 / (alpha - beta);
-    }
-    // ---- v = x * scal (stored), d_t = V_t(rk:m)^T v ---------------------------------------------------------
-    constexpr int RB2 = sizeof(T) == 8 ? 2 : 4, TB2 = 8;
-    T d[kNB];
-#pragma unroll
-    for (int t = 0; t < kNB; ++t) d[t] = 0;
-    if (tk != (T)0) {
-        for (int64_t ib = rk + tid; ib < m; ib += kPT * RB2) {
-            T v[RB2];
-            int64_t ii[RB2];
-#pragma unroll
-            for (int e = 0; e < RB2; ++e) {
-                const int64_t i = ib + kPT * e;
-                ii[e] = i < m ? i : (int64_t)rk;
-                const T xv = wc[ii[e]];
-                v[e] = i >= m ? (T)0 : (i == rk ? (T)1 : xv * scal);
-                if (i < m && i > rk) wc[i] = v[e];
-            }
-#pragma unroll
-            for (int t0 = 0; t0 < kNB; t0 += TB2) {
-                if (t0 < k) {
-                    T vv[RB2][TB2];
-#pragma unroll
-                    for (int u = 0; u < TB2; ++u) {
-                        const T *cp = shcol[t0 + u];
-#pragma unroll
-                        for (int e = 0; e < RB2; ++e) vv[e][u] = cp[ii[e]];
-                    }
-#pragma unroll
-                    for (int u = 0; u < TB2; ++u)
-#pragma unroll
-                        for (int e = 0; e < RB2; ++e) d[t0 + u] = fma(vv[e][u], v[e], d[t0 + u]);
+    ss = wave_sum_dpp(ss);
+    if (lane == 0) sh4[wv] = ss;
+    __syncthreads();
+    if (tid == 0) P.pss[blockIdx.x] = (sh4[0] + sh4[1]) + (sh4[2] + sh4[3]);
+}
+
+// Step C.  Two load rounds: (1) panel state, slab partial sums and this workgroup's target, (2) the target column and
+// the up-to-date pivot column (16-byte loads, issued before ?larfg is evaluated from round 1's data).
+template <typename T>
+__global__ __launch_bounds__(256) void k_qrb_step_c(Mat<T> w, int j0, int k, int nslab, int vec_ok, QrbPanel<T> P) {
+    constexpr int VL = 16 / sizeof(T);
+    typedef T vecT __attribute__((ext_vector_type(VL)));
+    __shared__ T shs[4];
+    __shared__ T shw[4];
+    QrbState *st = P.st;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int rk = j0 + k;
+    const int nxt = (k & 1) ^ 1;
+    const int64_t m = w.rows;
+    const int xoff = rk & (VL - 1);
+    // ---- round 1 ----------------------------------------------------------------------------------------------------
+    const int stopped = st->stopped;
+    const int ncand = st->ncand;
+    const int cpiv = st->piv[k];
+    const T part = (tid < nslab && tid < 64) ? P.pss[tid] : (T)0;
+    const T alpha = P.pss[64];
+    int pf_c = 0, pf_p = 0;
+    if ((int)blockIdx.x < (int)P.ncap) { pf_c = P.cand[blockIdx.x]; pf_p = P.cpos[nxt][blockIdx.x]; }
+    if (stopped) return;
+    const T *xb = P.xbuf + xoff;
+    T *vcol = w.p + (int64_t)cpiv * w.cs + rk;
+    const int64_t nrows = m - rk;
+    const int peel = vec_ok ? (int)min((int64_t)((VL - xoff) & (VL - 1)), nrows) : 0;
+    const int64_t nv = vec_ok ? (nrows - peel) / VL : 0;
+    const int64_t tail0 = peel + nv * VL;
+    T tk = 0, beta = 0, scal = 0;
+    bool have = false;
+    auto larfg = [&]() {  // ?larfg from the slab partial sums (every workgroup, identical); uniform call sites only
+        if (tid < 64) {
+            const T s = wave_sum_dpp(part);
+            if (tid == 0) {
+                const T xnorm = sqrt(s);
+                T tk_ = 0, beta_ = alpha, scal_ = 0;
+                if (xnorm != (T)0) {
+                    beta_ = -copysign(hypot(alpha, xnorm), alpha);
+                    tk_ = (beta_ - alpha) / beta_;
+                    scal_ = (T)1 / (alpha - beta_);
                 }
+                shs[0] = tk_; shs[1] = beta_; shs[2] = scal_;
             }
         }
-    }
-#pragma unroll
-    for (int t = 0; t < kNB; ++t)
-        if (t < k) {
-            const T s = wave_sum_dpp(d[t]);
-            if (lane == 0) shred[wv * kNB + t] = s;
+        __syncthreads();
+        tk = shs[0]; beta = shs[1]; scal = shs[2];
+        have = true;
+    };
+    // ---- one workgroup per target column: the candidates, then the panel's earlier reflectors -------------------------------
+    for (int tg = blockIdx.x; tg < ncand + k; tg += gridDim.x) {
+        const T *col;
+        if (tg < ncand) {
+            const int p = tg == (int)blockIdx.x ? pf_p : P.cpos[nxt][tg];
+            if (p <= rk) continue;  // pivoted (uniform over the workgroup, before any barrier)
+            col = w.p + (int64_t)(tg == (int)blockIdx.x ? pf_c : P.cand[tg]) * w.cs + rk;
+        } else {
+            col = w.p + (int64_t)st->piv[tg - ncand] * w.cs + rk;
         }
-    __syncthreads();
-    if (tid < k) {
-        T s = 0;
+        // round 2: the first four vectors per thread of the column and of x (4096 rows of f32 / 2048 of f64 per workgroup)
+        const vecT *cv = reinterpret_cast<const vecT *>(col + peel);
+        const vecT *xv = reinterpret_cast<const vecT *>(xb + peel);
+        vecT cq[4], xq[4];
 #pragma unroll
-        for (int i = 0; i < kPT / 64; ++i) s += shred[i * kNB + tid];
-        const T a = -tk * s;
-        shaux[tid] = a;
-        auxv[tid] = a;
-    }
-    if (tid == 0) {
-        wc[rk] = beta;
-        tau[rk] = tk;
-    }
-    __syncthreads();
-    // ---- column k of T (?larft): T(0:k, k) = T(0:k, 0:k) auxv, T(k, k) = tau_k ------------------------------
-    if (tid <= k) {
-        T s = tk;
-        if (tid < k) {
-            s = 0;
-            for (int q = tid; q < k; ++q) s = fma(Tm[tid + q * kNB], shaux[q], s);
+        for (int q = 0; q < 4; ++q) {
+            const int64_t v = tid + 256 * q;
+            const bool ok = v < nv;
+            cq[q] = ok ? cv[v] : vecT{};
+            xq[q] = ok ? xv[v] : vecT{};
         }
-        Tm[tid + k * kNB] = s;
+        const T c_diag = tid == 0 ? col[0] : (T)0;  // unit diagonal of the reflector
+        T c_head = 0, x_head = 0;
+        if (tid >= 1 && tid < peel) { c_head = col[tid]; x_head = xb[tid]; }
+        if (!have) larfg();
+        T a0 = c_diag, a1 = 0, a2 = 0, a3 = 0;
+        if (tk != (T)0) {
+            a1 = c_head * (x_head * scal);
+            for (int64_t r = max(tail0, (int64_t)1) + tid; r < nrows; r += 256) a1 = fma(col[r], xb[r] * scal, a1);
+#pragma unroll
+            for (int u = 0; u < VL; ++u) {
+                const bool diag0 = peel == 0 && u == 0 && tid == 0;  // vector 0, element 0 is row 0 when nothing was peeled
+                a0 = fma(cq[0][u], diag0 ? (T)0 : xq[0][u] * scal, a0);
+                a1 = fma(cq[1][u], xq[1][u] * scal, a1);
+                a2 = fma(cq[2][u], xq[2][u] * scal, a2);
+                a3 = fma(cq[3][u], xq[3][u] * scal, a3);
+            }
+            for (int64_t v = tid + 1024; v < nv; v += 256) {
+                const vecT c0 = cv[v];
+                const vecT x0 = xv[v];
+#pragma unroll
+                for (int u = 0; u < VL; ++u) a2 = fma(c0[u], x0[u] * scal, a2);
+            }
+        }
+        T g = wave_sum_dpp((a0 + a1) + (a2 + a3));
+        __syncthreads();  // shw of the previous target has been read
+        if (lane == 0) shw[wv] = g;
+        __syncthreads();
+        if (tid == 0) {
+            g = (shw[0] + shw[1]) + (shw[2] + shw[3]);
+            if (tg < ncand) P.G[tg] = g;
+            else P.gv[tg - ncand] = g;
+        }
+    }
+    if (!have) larfg();
+    if (blockIdx.x == 0 && tid == 0) { P.tau[rk] = tk; vcol[0] = beta; }
+    // ---- v stored: rows distributed over the workgroups (nobody reads the column itself in this launch) -----------------------
+    {
+        const int64_t nr = m - rk - 1;
+        const int64_t per = (nr + gridDim.x - 1) / gridDim.x;
+        const int64_t a0 = 1 + (int64_t)blockIdx.x * per, a1 = min(m - rk, a0 + per);
+        for (int64_t r = a0 + tid; r < a1; r += 256) vcol[r] = tk != (T)0 ? xb[r] * scal : xb[r];
     }
 }
 
-// ---------------------------------------------------------------------------
-// step k, parallel part: one wave per unpivoted candidate: F(c, k), row rk of the column, norm down-date
-// ---------------------------------------------------------------------------
+// panel end: rows j0 .. j0+kb-1 of R and the final norms of the candidates go back into the matrix / the norm array
 template <typename T>
-__global__ __launch_bounds__(256) void k_qrb_update(Mat<T> w, int j0, int k, const int *pos, T *vn1, const T *vn2, T *Fm, const int *cand, int *flag,
-                                                    QrbState *st, const T *tau, const T *auxv) {
-    __shared__ T shaux[kNB], shvrow[kNB];
-    if (st->stopped) return;
-    const int rk = j0 + k, ncand = st->ncand;
-    const int cpiv = st->piv[k];
-    const int lane = threadIdx.x & 63;
-    const int64_t m = w.rows;
-    if (threadIdx.x < k) {
-        shaux[threadIdx.x] = auxv[threadIdx.x];
-        shvrow[threadIdx.x] = w.p[(int64_t)st->piv[threadIdx.x] * w.cs + rk];
-    }
-    __syncthreads();
-    const T tk = tau[rk];
-    const T *v = w.p + (int64_t)cpiv * w.cs;
-    const int nw = gridDim.x * 4;
-    for (int ci = blockIdx.x * 4 + (threadIdx.x >> 6); ci < ncand; ci += nw) {
-        const int c = cand[ci];
-        if (pos[c] <= rk) continue;  // pivoted (wave-uniform)
-        T *x = w.p + (int64_t)c * w.cs;
-        // g = A(rk:m, c)^T v, v(rk) = 1
-        T a0 = 0, a1 = 0, a2 = 0, a3 = 0;
-        int64_t i = rk + lane;
-        if (lane == 0) { a0 = x[rk]; i += 64; }  // unit diagonal of the reflector
-        for (; i + 192 < m; i += 256) {
-            const T x0 = x[i], x1 = x[i + 64], x2 = x[i + 128], x3 = x[i + 192];
-            const T v0 = v[i], v1 = v[i + 64], v2 = v[i + 128], v3 = v[i + 192];
-            a0 = fma(x0, v0, a0); a1 = fma(x1, v1, a1); a2 = fma(x2, v2, a2); a3 = fma(x3, v3, a3);
-        }
-        for (; i < m; i += 64) a1 = fma(x[i], v[i], a1);
-        const T g = wave_sum_dpp((a0 + a1) + (a2 + a3));
-        const T ft = lane < k ? Fm[(int64_t)c * kNB + lane] : (T)0;
-        const T e = wave_sum_dpp(lane < k ? ft * shaux[lane] : (T)0);
-        const T fk = tk * g + e;
-        const T term = lane < k ? shvrow[lane] * ft : (T)0;
-        const T sr = wave_sum_dpp(term) + fk;
-        if (lane == 0) {
-            Fm[(int64_t)c * kNB + k] = fk;
-            const T a = x[rk] - sr;
-            x[rk] = a;
-            const T vn = vn1[c];
-            if (vn != (T)0) {
-                T temp = fabs(a) / vn;
-                temp = ((T)1 + temp) * ((T)1 - temp);
-                temp = temp > (T)0 ? temp : (T)0;
-                const T r = vn / vn2[c];
-                const T temp2 = temp * r * r;
-                if (temp2 <= NumB<T>::tol3z()) { flag[c] = 1; st->lsticc = 1; }
-                else vn1[c] = vn * sqrt(temp);
-            }
-        }
-    }
+__global__ __launch_bounds__(256) void k_qrb_scatter(Mat<T> w, int j0, int kb, QrbPanel<T> P, T *vn1) {
+    const int ci = blockIdx.x * 256 + threadIdx.x;
+    if (ci >= P.st->ncand) return;
+    const int c = P.cand[ci];
+    const int p = P.pos[c];
+    const int buf = P.st->pad0;
+    T *x = w.p + (int64_t)c * w.cs + j0;
+    const int lim = min(kb, p - j0);  // rows of R above the column's own diagonal position
+    for (int kk = 0; kk < lim; ++kk) x[kk] = P.Rrow[(int64_t)kk * P.ncap + ci];
+    if (p >= j0 + kb) vn1[c] = P.cvn[buf][ci];
 }
 
 // Vp(i, t) = v_t(j0 + i): zeros above the diagonal, one on it, the reflector below  (rows x kb, column-major)
@@ -545,74 +737,162 @@ bool geqp3_blocked_supported(int64_t m, int64_t n, int64_t kmax) {
     return on && m >= 128 && n >= 128 && kmax >= 8 && n < (int64_t)1 << 30 && m < (int64_t)1 << 30;
 }
 
+// One factorization as a resumable job: issue() enqueues a panel's kernels and the read-back of its state, finish() -- once
+// the stream has been synchronised -- enqueues the panel-end kernels and says whether the factorization is complete.  A host
+// that drives several matrices (rc_batch_column_id_*) issues all of them, waits once, finishes all of them: the per-panel
+// waits of different matrices overlap.  All buffers come from the context's arena (no reset while the job is alive).
+template <typename T>
+struct BlockedQrcpJob {
+    rc_context *c;
+    Mat<T> w;
+    int64_t m, n, kmax, j0 = 0, cwant, ldy;
+    int64_t *jpvt;
+    T *tau;
+    int *pos, *cand, *flag;
+    unsigned char *is_cand;
+    T *vn1, *vn2, *Fm, *Tm, *auxv, *tsc, *Y;
+    QrbPanel<T> P;
+    QrbState *st;
+    QrbState *host_st;  // pinned
+    Mat<T> vp;
+    int vec_ok;
+    int nbp = 0;
+};
+
+template <typename T>
+BlockedQrcpJob<T> *qrb_begin(rc_context *c, Mat<T> w, int64_t kmax, int64_t *jpvt, T *tau) {
+    RC_REQUIRE(w.rs == 1, RC_LAYOUT_ERROR, "geqp3_blocked: working matrix must be column-major");
+    RC_REQUIRE(!c->capturing, RC_RUNTIME_ERROR, "geqp3_blocked: reads one scalar back per panel, not capturable");
+    auto *J = new BlockedQrcpJob<T>();
+    J->c = c; J->w = w; J->jpvt = jpvt; J->tau = tau;
+    const int64_t m = w.rows, n = w.cols;
+    J->m = m; J->n = n;
+    J->kmax = std::min(kmax, std::min(m, n));
+    J->pos = c->alloc<int>((size_t)n);
+    J->cand = c->alloc<int>((size_t)n);
+    J->flag = c->alloc<int>((size_t)n);
+    J->is_cand = c->alloc<unsigned char>((size_t)n);
+    J->vn1 = c->alloc<T>((size_t)n);
+    J->vn2 = c->alloc<T>((size_t)n);
+    J->Fm = c->alloc<T>((size_t)n * kNB);
+    J->Tm = c->alloc<T>((size_t)kNB * kNB);
+    J->auxv = c->alloc<T>(kNB);
+    J->tsc = c->alloc<T>(4);
+    QrbPanel<T> &P = J->P;
+    P.jpvt = jpvt; P.pos = J->pos; P.cand = J->cand;
+    P.cpos[0] = c->alloc<int>((size_t)n); P.cpos[1] = c->alloc<int>((size_t)n);
+    P.cvn[0] = c->alloc<T>((size_t)n); P.cvn[1] = c->alloc<T>((size_t)n);
+    P.vn2 = J->vn2; P.Fm = J->Fm;
+    P.G = c->alloc<T>((size_t)n); P.gv = c->alloc<T>(kNB);
+    P.Rrow = c->alloc<T>((size_t)kNB * n); P.ncap = n;
+    P.xbuf = c->alloc<T>((size_t)m + 16); P.pss = c->alloc<T>(80);
+    P.flag = J->flag; P.tsc = J->tsc; P.tau = tau; P.auxv = J->auxv; P.Tm = J->Tm;
+    J->st = reinterpret_cast<QrbState *>(c->alloc_bytes(sizeof(QrbState)));
+    P.st = J->st;
+    J->vp = colmajor(c->alloc<T>((size_t)even_ld(m) * kNB), m, kNB, even_ld(m));
+    J->ldy = even_ld(n);
+    J->Y = c->alloc<T>((size_t)kNB * J->ldy);
+    if (c->pinned_size < sizeof(QrbState)) {
+        if (c->pinned) RC_HIP(hipHostFree(c->pinned));
+        c->pinned = nullptr; c->pinned_size = 0;
+        RC_HIP(hipHostMalloc(&c->pinned, 1 << 16, hipHostMallocDefault));
+        c->pinned_size = 1 << 16;
+    }
+    J->host_st = reinterpret_cast<QrbState *>(c->pinned);
+    RC_HIP(hipMemsetAsync(J->Fm, 0, (size_t)n * kNB * sizeof(T), c->stream));  // step A reads whole F rows: keep them finite
+    J->vec_ok = (w.cs % (16 / (int64_t)sizeof(T)) == 0 && reinterpret_cast<uintptr_t>(w.p) % 16 == 0) ? 1 : 0;
+    hipLaunchKernelGGL(k_qrb_init<T>, dim3((unsigned)std::min<int64_t>(cdivb(n, 4), 8192)), dim3(256), 0, c->stream, w, jpvt, J->pos, J->vn1, J->vn2, J->flag);
+    // candidate budget: about RC_QRCP_CAND_MB of column data (L2-resident across the steps of a panel), at least 4 NB columns
+    static const int cand_mb = env_int_b("RC_QRCP_CAND_MB", 8);
+    J->cwant = std::max<int64_t>(4 * kNB, ((int64_t)cand_mb << 20) / (int64_t)(sizeof(T) * (size_t)std::max<int64_t>(m, 1)));
+    if (cand_mb <= 0) J->cwant = n;  // plain ?laqps
+    return J;
+}
+
+template <typename T>
+void qrb_issue(BlockedQrcpJob<T> *J) {
+    rc_context *c = J->c;
+    const int64_t m = J->m, n = J->n, j0 = J->j0;
+    const int nbp = (int)std::min<int64_t>(kNB, J->kmax - j0);
+    J->nbp = nbp;
+    const int64_t cw = std::min<int64_t>(J->cwant, n - j0);
+    hipLaunchKernelGGL(k_qrb_select<T>, dim3(1), dim3(1024), 0, c->stream, (int)n, (int)j0, (int)cw, J->pos, J->vn1, J->cand, J->is_cand, J->st, J->tsc, J->P.cpos[0],
+                       J->P.cvn[0]);
+    // step A: every workgroup re-evaluates the per-candidate bookkeeping, so few workgroups when the candidates are many
+    const int64_t cbound = std::min<int64_t>(n - j0, 2 * cw);
+    const unsigned grid_a = (unsigned)std::max<int64_t>(4, std::min<int64_t>(std::min<int64_t>(64, cdivb(m - j0, 64)), 32768 / std::max<int64_t>(cbound, 1)));
+    const unsigned grid_c = (unsigned)std::max<int64_t>(1, std::min<int64_t>(cbound + kNB, 4096));
+    for (int k = 0; k < nbp; ++k) {
+        hipLaunchKernelGGL(k_qrb_step_a<T>, dim3(grid_a), dim3(256), 0, c->stream, J->w, (int)j0, k, 0, J->P);
+        hipLaunchKernelGGL(k_qrb_step_c<T>, dim3(grid_c), dim3(256), 0, c->stream, J->w, (int)j0, k, (int)grid_a, J->vec_ok, J->P);
+    }
+    hipLaunchKernelGGL(k_qrb_step_a<T>, dim3(1), dim3(256), 0, c->stream, J->w, (int)j0, nbp, 1, J->P);
+    RC_HIP(hipMemcpyAsync(J->host_st, J->st, sizeof(QrbState), hipMemcpyDeviceToHost, c->stream));
+}
+
+// to be called after the context's stream has been synchronised since qrb_issue(); true = factorization complete
+template <typename T>
+bool qrb_finish(BlockedQrcpJob<T> *J) {
+    rc_context *c = J->c;
+    const QrbState h = *J->host_st;
+    const int64_t m = J->m, n = J->n, j0 = J->j0;
+    const int kb = h.kb;  // (the final step A always stops the panel)
+    RC_REQUIRE(h.stopped && kb >= 1 && kb <= J->nbp, RC_PIVOTED_QR_ERROR, "geqp3_blocked: panel at %lld made %d steps", (long long)j0, kb);
+    const int64_t rows = m - j0;
+    const bool last = j0 + kb >= J->kmax;
+    Mat<T> w = J->w;
+    Mat<T> vpp = Mat<T>(J->vp.p, rows, kb, 1, J->vp.cs);
+    hipLaunchKernelGGL(k_qrb_build_vp<T>, dim3((unsigned)std::min<int64_t>(cdivb(rows, 256), 64), (unsigned)kb), dim3(256), 0, c->stream, w, (int)j0, J->st, vpp);
+    if (h.have_noncand) {
+        // Y = V^T A(j0:m, :) for every column: one read pass (MFMA GEMM); used for the non-candidates only
+        Mat<T> ym = rowmajor(J->Y, kb, n, J->ldy);
+        gemm<T>(c, 1, vpp.t(), w.sub(j0, rows, 0, n), 0, ym);
+    }
+    hipLaunchKernelGGL(k_qrb_scatter<T>, dim3((unsigned)cdivb(std::max(h.ncand, 1), 256)), dim3(256), 0, c->stream, w, (int)j0, kb, J->P, J->vn1);
+    hipLaunchKernelGGL(k_qrb_finish<T>, dim3((unsigned)cdivb(n, 256)), dim3(256), 0, c->stream, w, (int)j0, kb, J->pos, J->is_cand, J->vn1, J->vn2, J->Fm, J->Y, J->ldy,
+                       J->Tm, vpp, J->flag);
+    if (!last && rows - kb > 0) {
+        // block update of everything below the panel, written as the transposed product so that the lanes of the
+        // MFMA accumulator run along the column-major matrix' contiguous dimension:
+        //   A(j0+kb:m, :)^T -= F(:, 0:kb) V(kb:, 0:kb)^T
+        Mat<T> ft = Mat<T>(J->Fm, n, kb, kNB, 1);
+        gemm<T>(c, (T)-1, ft, vpp.sub(kb, rows - kb, 0, kb).t(), (T)1, w.sub(j0 + kb, rows - kb, 0, n).t());
+        hipLaunchKernelGGL(k_qrb_renorm<T>, dim3((unsigned)std::min<int64_t>(cdivb(n, 4), 4096)), dim3(256), 0, c->stream, w, (int)(j0 + kb), J->pos, J->flag, J->vn1,
+                           J->vn2);
+    }
+    // a panel that the tau test ended early means the candidate set was too small for this spectrum
+    if (h.stop_tau && kb < J->nbp / 2) J->cwant = std::min<int64_t>(n, J->cwant * 2);
+    J->j0 += kb;
+    return J->j0 >= J->kmax;
+}
+
+template <typename T>
+void qrb_end(BlockedQrcpJob<T> *J) { delete J; }
+
 // w: m x n column-major working matrix (overwritten with the ?geqp3 output format: R on and above the
 // diagonal in position order, reflectors below, columns never moved); jpvt: n; tau: kmax
 template <typename T>
 void geqp3_blocked(rc_context *c, Mat<T> w, int64_t kmax, int64_t *jpvt, T *tau) {
-    RC_REQUIRE(w.rs == 1, RC_LAYOUT_ERROR, "geqp3_blocked: working matrix must be column-major");
-    RC_REQUIRE(!c->capturing, RC_RUNTIME_ERROR, "geqp3_blocked: reads one scalar back per panel, not capturable");
-    const int64_t m = w.rows, n = w.cols;
-    kmax = std::min(kmax, std::min(m, n));
-    if (kmax <= 0) return;
-    ProfScope ps(c, "op:geqp3_blocked %lldx%lld k=%lld", (long long)m, (long long)n, (long long)kmax);
+    if (std::min(kmax, std::min(w.rows, w.cols)) <= 0) return;
+    ProfScope ps(c, "op:geqp3_blocked %lldx%lld k=%lld", (long long)w.rows, (long long)w.cols, (long long)kmax);
     ArenaMark mark(c);
-    int *pos = c->alloc<int>((size_t)n);
-    int *cand = c->alloc<int>((size_t)n);
-    int *flag = c->alloc<int>((size_t)n);
-    unsigned char *is_cand = c->alloc<unsigned char>((size_t)n);
-    T *vn1 = c->alloc<T>((size_t)n), *vn2 = c->alloc<T>((size_t)n);
-    T *Fm = c->alloc<T>((size_t)n * kNB);
-    T *Tm = c->alloc<T>((size_t)kNB * kNB);
-    T *auxv = c->alloc<T>(kNB);
-    T *tsc = c->alloc<T>(4);
-    QrbState *st = reinterpret_cast<QrbState *>(c->alloc_bytes(sizeof(QrbState)));
-    Mat<T> vp = colmajor(c->alloc<T>((size_t)even_ld(m) * kNB), m, kNB, even_ld(m));
-    T *Y = c->alloc<T>((size_t)kNB * even_ld(n));
-    const int64_t ldy = even_ld(n);
-
-    hipLaunchKernelGGL(k_qrb_init<T>, dim3((unsigned)std::min<int64_t>(cdivb(n, 4), 8192)), dim3(256), 0, c->stream, w, jpvt, pos, vn1, vn2, flag);
-    // candidate budget: about RC_QRCP_CAND_MB of column data (L2-resident across the steps of a panel), at least 4 NB columns
-    static const int cand_mb = env_int_b("RC_QRCP_CAND_MB", 8);
-    int64_t cwant = std::max<int64_t>(4 * kNB, ((int64_t)cand_mb << 20) / (int64_t)(sizeof(T) * (size_t)std::max<int64_t>(m, 1)));
-    if (cand_mb <= 0) cwant = n;  // plain ?laqps
-    int64_t j0 = 0;
-    while (j0 < kmax) {
-        const int nbp = (int)std::min<int64_t>(kNB, kmax - j0);
-        const int64_t cw = std::min<int64_t>(cwant, n - j0);
-        hipLaunchKernelGGL(k_qrb_select<T>, dim3(1), dim3(1024), 0, c->stream, (int)n, (int)j0, (int)cw, pos, vn1, cand, is_cand, st, tsc);
-        const unsigned grid2 = (unsigned)std::max<int64_t>(1, std::min<int64_t>(cdivb(n - j0, 4), cdivb(2 * cw, 4)));
-        for (int k = 0; k < nbp; ++k) {
-            hipLaunchKernelGGL(k_qrb_pivot<T>, dim3(1), dim3(kPT), 0, c->stream, w, (int)j0, k, jpvt, pos, vn1, Fm, cand, st, tsc, tau, auxv, Tm);
-            hipLaunchKernelGGL(k_qrb_update<T>, dim3(grid2), dim3(256), 0, c->stream, w, (int)j0, k, pos, vn1, vn2, Fm, cand, flag, st, tau, auxv);
-        }
-        QrbState h;
-        RC_HIP(hipMemcpyAsync(&h, st, sizeof(QrbState), hipMemcpyDeviceToHost, c->stream));
+    BlockedQrcpJob<T> *J = qrb_begin<T>(c, w, kmax, jpvt, tau);
+    struct Guard { BlockedQrcpJob<T> *j; ~Guard() { qrb_end(j); } } guard{J};
+    for (;;) {
+        qrb_issue(J);
         RC_HIP(hipStreamSynchronize(c->stream));
-        const int kb = h.stopped ? h.kb : nbp;
-        RC_REQUIRE(kb >= 1 && kb <= nbp, RC_PIVOTED_QR_ERROR, "geqp3_blocked: panel at %lld made %d steps", (long long)j0, kb);
-        const int64_t rows = m - j0;
-        const bool last = j0 + kb >= kmax;
-        Mat<T> vpp = Mat<T>(vp.p, rows, kb, 1, vp.cs);
-        hipLaunchKernelGGL(k_qrb_build_vp<T>, dim3((unsigned)std::min<int64_t>(cdivb(rows, 256), 64), (unsigned)kb), dim3(256), 0, c->stream, w, (int)j0, st, vpp);
-        if (h.have_noncand) {
-            // Y = V^T A(j0:m, :) for every column: one read pass (MFMA GEMM); used for the non-candidates only
-            Mat<T> ym = rowmajor(Y, kb, n, ldy);
-            gemm<T>(c, 1, vpp.t(), w.sub(j0, rows, 0, n), 0, ym);
-        }
-        hipLaunchKernelGGL(k_qrb_finish<T>, dim3((unsigned)cdivb(n, 256)), dim3(256), 0, c->stream, w, (int)j0, kb, pos, is_cand, vn1, vn2, Fm, Y, ldy, Tm, vpp, flag);
-        if (!last && rows - kb > 0) {
-            // block update of everything below the panel, written as the transposed product so that the lanes of the
-            // MFMA accumulator run along the column-major matrix' contiguous dimension:
-            //   A(j0+kb:m, :)^T -= F(:, 0:kb) V(kb:, 0:kb)^T
-            Mat<T> ft = Mat<T>(Fm, n, kb, kNB, 1);
-            gemm<T>(c, (T)-1, ft, vpp.sub(kb, rows - kb, 0, kb).t(), (T)1, w.sub(j0 + kb, rows - kb, 0, n).t());
-            hipLaunchKernelGGL(k_qrb_renorm<T>, dim3((unsigned)std::min<int64_t>(cdivb(n, 4), 4096)), dim3(256), 0, c->stream, w, (int)(j0 + kb), pos, flag, vn1, vn2);
-        }
-        // a panel that the tau test ended early means the candidate set was too small for this spectrum
-        if (h.stopped && h.stop_tau && kb < nbp / 2) cwant = std::min<int64_t>(n, cwant * 2);
-        j0 += kb;
+        if (qrb_finish(J)) break;
     }
 }
+
+#define RC_INST_JOB(T)                                                                           \
+    template BlockedQrcpJob<T> *qrb_begin<T>(rc_context *, Mat<T>, int64_t, int64_t *, T *);     \
+    template void qrb_issue<T>(BlockedQrcpJob<T> *);                                             \
+    template bool qrb_finish<T>(BlockedQrcpJob<T> *);                                            \
+    template void qrb_end<T>(BlockedQrcpJob<T> *);
+RC_INST_JOB(double)
+RC_INST_JOB(float)
+#undef RC_INST_JOB
 
 template bool geqp3_blocked_supported<double>(int64_t, int64_t, int64_t);
 template bool geqp3_blocked_supported<float>(int64_t, int64_t, int64_t);

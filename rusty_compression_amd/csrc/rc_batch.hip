@@ -1,0 +1,303 @@
+// Batches of independent matrices (BASELINE.json configs[4]: 64 x (4096 x 4096 f32), rank-64 column ID, 8 per GPU)
+// and the one exchange step of the path: the gather of the finished factor blocks over RCCL.
+//
+// Reference call sequence per matrix (examples/interpolative_decomposition.rs:25-32):
+//     QR::compute_from(a) -> compress(RANK(k)) -> column_id()
+// (src/qr.rs:354-362 via pivoted_qr, :169-184, :270-309).  The reference has no batch or communication layer: it is
+// single-process host code; SURVEY.md section 8(b) / 8(e) define these entry points.
+//
+// rc_batch_column_id_*: the matrices of one GPU are spread over the caller's contexts (one stream each) and advanced in
+// lock step: every lane issues one ?laqps panel, the host waits ONCE for all lanes (the panel length is data dependent),
+// every lane issues its panel-end kernels -- so the per-panel waits and the latency-bound pivot steps of different
+// matrices overlap.  Results land in one packed device buffer, which is exactly what rc_comm_gather moves.
+//
+// RCCL is opened at run time (dlopen) so that the library has no link-time dependency on it: hosts that never gather,
+// and the CPU-side symbol tests, do not need it.  Inside a PyTorch process the soname resolves to the copy torch loaded.
+#include "rc_common.hpp"
+
+#include <dlfcn.h>
+#include <rccl/rccl.h>
+
+#include <algorithm>
+#include <mutex>
+
+using namespace rc;
+
+namespace {
+
+struct DeviceGuardB {
+    int prev = -1;
+    explicit DeviceGuardB(int dev) {
+        (void)hipGetDevice(&prev);
+        if (prev != dev) (void)hipSetDevice(dev);
+        else prev = -1;
+    }
+    ~DeviceGuardB() { if (prev >= 0) (void)hipSetDevice(prev); }
+};
+
+inline size_t align8(size_t x) { return (x + 7) & ~(size_t)7; }
+
+template <typename T>
+Mat<T> tmp_cm(rc_context *c, int64_t rows, int64_t cols) {
+    int64_t ld = even_ld(std::max<int64_t>(rows, 1));
+    if (ld % 4) ld += 4 - ld % 4;  // 16-byte aligned columns: the blocked QRCP's vector loads
+    return colmajor(c->alloc<T>((size_t)ld * std::max<int64_t>(cols, 1)), rows, cols, ld);
+}
+
+// column ID from the factorization in the ?geqp3 output format (same steps as column_id_rank in rc_api.hip)
+template <typename T>
+void finish_column_id(rc_context *c, Mat<T> w, int64_t k, const T *tau, int64_t *ind, Mat<T> cm, Mat<T> z) {
+    const int64_t m = w.rows, n = w.cols;
+    Mat<T> r = rowmajor(c->alloc<T>((size_t)k * even_ld(n)), k, n, even_ld(n));
+    extract_r(c, w, ind, r);
+    Mat<T> q = tmp_cm<T>(c, m, k);
+    form_q(c, w, ind, tau, k, q);
+    // QRTraits::column_id (src/qr.rs:270-309): Z = [I | R11^-1 R12] P^T, C = Q R11
+    int64_t *inv = c->alloc<int64_t>((size_t)n);
+    invert_perm(c, ind, n, inv);
+    Mat<T> zt = rowmajor(c->alloc<T>((size_t)k * even_ld(n)), k, n, even_ld(n));
+    if (k == n) {
+        gemm<T>(c, 1, q, r, 0, cm);
+        fill_identity(c, zt);
+    } else {
+        fill_identity(c, zt.sub(0, k, 0, k));
+        copy_mat(c, r.sub(0, k, k, n - k), zt.sub(0, k, k, n - k));
+        trsm_upper(c, r.sub(0, k, 0, k), zt.sub(0, k, k, n - k));
+        gemm<T>(c, 1, q, r.sub(0, k, 0, k), 0, cm);
+    }
+    gather_cols(c, zt, inv, z);
+}
+
+template <typename T>
+void batch_column_id(rc_context *const *ctxs, int nctx, const rc_matrix *mats, int count, int64_t k, void *packed) {
+    RC_REQUIRE(nctx >= 1 && count >= 0 && k >= 1, RC_INVALID_ARGUMENT, "batch_column_id: need >= 1 context, k >= 1");
+    if (count == 0) return;
+    RC_REQUIRE(mats != nullptr && packed != nullptr, RC_INVALID_ARGUMENT, "batch_column_id: null argument");
+    const int64_t m = mats[0].rows, n = mats[0].cols;
+    for (int i = 0; i < count; ++i)
+        RC_REQUIRE(mats[i].rows == m && mats[i].cols == n && mats[i].data, RC_INVALID_ARGUMENT, "batch_column_id: all matrices must have the shape of the first");
+    RC_REQUIRE(k <= std::min(m, n), RC_INVALID_ARGUMENT, "batch_column_id: rank %lld exceeds min(m, n)", (long long)k);
+    for (int l = 0; l < nctx; ++l) RC_REQUIRE(ctxs[l] && !ctxs[l]->capturing, RC_INVALID_ARGUMENT, "batch_column_id: bad context");
+    const size_t per = rc_batch_packed_bytes(m, n, k, (int32_t)sizeof(T));
+    struct Lane {
+        rc_context *c = nullptr;
+        int idx = -1;
+        Mat<T> w;
+        T *tau = nullptr;
+        int64_t *ind = nullptr;
+        BlockedQrcpJob<T> *job = nullptr;
+        bool active = false;
+    };
+    std::vector<Lane> lanes((size_t)nctx);
+    struct Cleanup {
+        std::vector<Lane> &l;
+        ~Cleanup() { for (auto &x : l) if (x.job) { qrb_end(x.job); x.job = nullptr; } }
+    } cleanup{lanes};
+    auto slot = [&](int idx) { return static_cast<char *>(packed) + (size_t)idx * per; };
+    auto post = [&](Lane &ln) {
+        char *base = slot(ln.idx);
+        Mat<T> cm = rowmajor(reinterpret_cast<T *>(base), m, k, k);
+        Mat<T> z = rowmajor(reinterpret_cast<T *>(base) + (size_t)m * k, k, n, n);
+        finish_column_id<T>(ln.c, ln.w, k, ln.tau, ln.ind, cm, z);
+    };
+    for (int base = 0; base < count; base += nctx) {
+        int nact = 0;
+        for (int l = 0; l < nctx && base + l < count; ++l) {
+            Lane &ln = lanes[(size_t)l];
+            ln.c = ctxs[l];
+            ln.idx = base + l;
+            DeviceGuardB dg(ln.c->device);
+            ln.c->reset_arena();
+            ln.w = tmp_cm<T>(ln.c, m, n);
+            ln.tau = ln.c->template alloc<T>((size_t)k);
+            ln.ind = reinterpret_cast<int64_t *>(slot(ln.idx) + align8(((size_t)m * k + (size_t)k * n) * sizeof(T)));
+            copy_mat(ln.c, from_c<T>(mats[ln.idx]), ln.w);  // the reference's F-order working copy (pivoted_qr.rs:28-29)
+            if (ln.c->opt_blocked && geqp3_blocked_supported<T>(m, n, k)) {
+                ln.job = qrb_begin<T>(ln.c, ln.w, k, ln.ind, ln.tau);
+                ln.active = true;
+                ++nact;
+            } else {  // small shapes: the per-step chain, nothing to interleave
+                T *vn = ln.c->template alloc<T>((size_t)(2 * n));
+                geqp3_inplace(ln.c, ln.w, k, true, ln.ind, ln.tau, vn);
+                post(ln);
+                ln.active = false;
+            }
+        }
+        while (nact > 0) {
+            for (auto &ln : lanes)
+                if (ln.active) { DeviceGuardB dg(ln.c->device); qrb_issue(ln.job); }
+            // one wait for all lanes: an event on every stream first (see rc_synchronize_all)
+            std::vector<rc_context *> act;
+            for (auto &ln : lanes)
+                if (ln.active) act.push_back(ln.c);
+            RC_REQUIRE(rc_synchronize_all(act.data(), (int32_t)act.size()) == RC_OK, RC_RUNTIME_ERROR, "batch_column_id: wait failed");
+            for (auto &ln : lanes) {
+                if (!ln.active) continue;
+                DeviceGuardB dg(ln.c->device);
+                if (qrb_finish(ln.job)) {
+                    qrb_end(ln.job);
+                    ln.job = nullptr;
+                    ln.active = false;
+                    --nact;
+                    post(ln);
+                }
+            }
+        }
+    }
+    std::vector<rc_context *> all(ctxs, ctxs + std::min(nctx, count));
+    RC_REQUIRE(rc_synchronize_all(all.data(), (int32_t)all.size()) == RC_OK, RC_RUNTIME_ERROR, "batch_column_id: wait failed");
+    for (rc_context *c : all) {
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) fail(RC_RUNTIME_ERROR, "kernel launch failed: %s", hipGetErrorString(e));
+        (void)c;
+    }
+}
+
+template <typename F>
+rc_status guarded_b(rc_context *ctx, F &&f) {
+    if (!ctx) return RC_INVALID_ARGUMENT;
+    try {
+        f();
+        return RC_OK;
+    } catch (const Error &e) {
+        ctx->last_error = e.msg;
+        return e.code;
+    } catch (const std::exception &e) {
+        ctx->last_error = e.what();
+        return RC_RUNTIME_ERROR;
+    }
+}
+
+// ---------------------------------------------------------------- RCCL, opened at run time
+struct Rccl {
+    void *handle = nullptr;
+    ncclResult_t (*GetUniqueId)(ncclUniqueId *) = nullptr;
+    ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*Send)(const void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*Recv)(void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*GroupStart)() = nullptr;
+    ncclResult_t (*GroupEnd)() = nullptr;
+    const char *(*GetErrorString)(ncclResult_t) = nullptr;
+    std::string error;
+};
+
+Rccl *rccl() {
+    static Rccl r;
+    static std::once_flag once;
+    std::call_once(once, [] {
+        for (const char *name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+            r.handle = dlopen(name, RTLD_NOW | RTLD_LOCAL);
+            if (r.handle) break;
+        }
+        if (!r.handle) { r.error = std::string("librccl could not be opened: ") + dlerror(); return; }
+        auto sym = [&](const char *n) { void *p = dlsym(r.handle, n); if (!p && r.error.empty()) r.error = std::string("RCCL symbol missing: ") + n; return p; };
+        r.GetUniqueId = reinterpret_cast<decltype(r.GetUniqueId)>(sym("ncclGetUniqueId"));
+        r.CommInitRank = reinterpret_cast<decltype(r.CommInitRank)>(sym("ncclCommInitRank"));
+        r.CommDestroy = reinterpret_cast<decltype(r.CommDestroy)>(sym("ncclCommDestroy"));
+        r.Send = reinterpret_cast<decltype(r.Send)>(sym("ncclSend"));
+        r.Recv = reinterpret_cast<decltype(r.Recv)>(sym("ncclRecv"));
+        r.GroupStart = reinterpret_cast<decltype(r.GroupStart)>(sym("ncclGroupStart"));
+        r.GroupEnd = reinterpret_cast<decltype(r.GroupEnd)>(sym("ncclGroupEnd"));
+        r.GetErrorString = reinterpret_cast<decltype(r.GetErrorString)>(sym("ncclGetErrorString"));
+    });
+    return &r;
+}
+
+}  // namespace
+
+struct rc_comm {
+    ncclComm_t comm = nullptr;
+    int world = 1, rank = 0, device = 0;
+    std::string last_error;
+};
+
+extern "C" {
+
+size_t rc_batch_packed_bytes(int64_t m, int64_t n, int64_t k, int32_t elem_size) {
+    if (m < 0 || n < 0 || k < 0 || elem_size <= 0) return 0;
+    return align8(((size_t)m * (size_t)k + (size_t)k * (size_t)n) * (size_t)elem_size) + (size_t)n * 8;
+}
+
+rc_status rc_batch_shard_range(int64_t n_items, int32_t world, int32_t rank, int64_t *start, int64_t *count) {
+    if (n_items < 0 || world < 1 || rank < 0 || rank >= world || !start || !count) return RC_INVALID_ARGUMENT;
+    const int64_t base = n_items / world, extra = n_items % world;
+    *start = rank * base + std::min<int64_t>(rank, extra);
+    *count = base + (rank < extra ? 1 : 0);
+    return RC_OK;
+}
+
+rc_status rc_batch_column_id_f64(rc_context *const *ctxs, int32_t nctx, const rc_matrix *mats, int32_t count, int64_t k, void *packed) {
+    if (!ctxs || nctx < 1 || !ctxs[0]) return RC_INVALID_ARGUMENT;
+    return guarded_b(ctxs[0], [&] { batch_column_id<double>(ctxs, nctx, mats, count, k, packed); });
+}
+rc_status rc_batch_column_id_f32(rc_context *const *ctxs, int32_t nctx, const rc_matrix *mats, int32_t count, int64_t k, void *packed) {
+    if (!ctxs || nctx < 1 || !ctxs[0]) return RC_INVALID_ARGUMENT;
+    return guarded_b(ctxs[0], [&] { batch_column_id<float>(ctxs, nctx, mats, count, k, packed); });
+}
+
+rc_status rc_comm_unique_id(void *id128) {
+    if (!id128) return RC_INVALID_ARGUMENT;
+    Rccl *r = rccl();
+    if (!r->error.empty()) return RC_RUNTIME_ERROR;
+    ncclUniqueId id;
+    if (r->GetUniqueId(&id) != ncclSuccess) return RC_RUNTIME_ERROR;
+    static_assert(sizeof(ncclUniqueId) == 128, "ncclUniqueId is 128 bytes");
+    std::memcpy(id128, &id, sizeof(id));
+    return RC_OK;
+}
+
+rc_status rc_comm_init(rc_comm **comm, int32_t world, int32_t rank, const void *id128, int32_t device) {
+    if (!comm) return RC_INVALID_ARGUMENT;
+    *comm = nullptr;
+    if (world < 1 || rank < 0 || rank >= world || !id128) return RC_INVALID_ARGUMENT;
+    Rccl *r = rccl();
+    if (!r->error.empty()) return RC_RUNTIME_ERROR;
+    DeviceGuardB dg(device);
+    ncclUniqueId id;
+    std::memcpy(&id, id128, sizeof(id));
+    rc_comm *c = new rc_comm();
+    c->world = world; c->rank = rank; c->device = device;
+    if (r->CommInitRank(&c->comm, world, id, rank) != ncclSuccess) { delete c; return RC_RUNTIME_ERROR; }
+    *comm = c;
+    return RC_OK;
+}
+
+const char *rc_comm_last_error_message(const rc_comm *comm) {
+    if (comm) return comm->last_error.c_str();
+    return rccl()->error.c_str();
+}
+
+// Gather `bytes_per_rank` bytes from every rank into recv[rank * bytes_per_rank ...] on `root`, on the context's stream
+// (asynchronous; grouped ncclSend / ncclRecv: every peer uses its own direct xGMI link to the root).
+rc_status rc_comm_gather(rc_comm *comm, rc_context *ctx, const void *send, void *recv, size_t bytes_per_rank, int32_t root) {
+    if (!comm || !ctx || root < 0 || root >= comm->world) return RC_INVALID_ARGUMENT;
+    if (bytes_per_rank == 0) return RC_OK;
+    if (!send || (comm->rank == root && !recv)) return RC_INVALID_ARGUMENT;
+    Rccl *r = rccl();
+    DeviceGuardB dg(comm->device);
+    auto chk = [&](ncclResult_t e) {
+        if (e == ncclSuccess) return true;
+        comm->last_error = r->GetErrorString ? r->GetErrorString(e) : "RCCL error";
+        ctx->last_error = comm->last_error;
+        return false;
+    };
+    bool ok = chk(r->GroupStart());
+    if (ok && comm->rank == root)
+        for (int p = 0; ok && p < comm->world; ++p)
+            ok = chk(r->Recv(static_cast<char *>(recv) + (size_t)p * bytes_per_rank, bytes_per_rank, ncclUint8, p, comm->comm, ctx->stream));
+    if (ok) ok = chk(r->Send(send, bytes_per_rank, ncclUint8, root, comm->comm, ctx->stream));
+    const bool ended = chk(r->GroupEnd());
+    return ok && ended ? RC_OK : RC_RUNTIME_ERROR;
+}
+
+rc_status rc_comm_destroy(rc_comm *comm) {
+    if (!comm) return RC_OK;
+    Rccl *r = rccl();
+    DeviceGuardB dg(comm->device);
+    if (comm->comm && r->CommDestroy) (void)r->CommDestroy(comm->comm);
+    delete comm;
+    return RC_OK;
+}
+
+}  // extern "C"

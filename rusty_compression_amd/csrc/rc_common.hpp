@@ -213,6 +213,12 @@ template <typename T> void geqp3_inplace(rc_context *c, Mat<T> w, int64_t kmax, 
 // format as geqp3_inplace; reads one small struct back per panel (not capturable in a hipGraph)
 template <typename T> bool geqp3_blocked_supported(int64_t m, int64_t n, int64_t kmax);
 template <typename T> void geqp3_blocked(rc_context *c, Mat<T> w, int64_t kmax, int64_t *jpvt, T *tau);
+// the same factorization as a resumable job (one host wait per panel): begin -> { issue, <stream synchronised>, finish } ... -> end
+template <typename T> struct BlockedQrcpJob;
+template <typename T> BlockedQrcpJob<T> *qrb_begin(rc_context *c, Mat<T> w, int64_t kmax, int64_t *jpvt, T *tau);
+template <typename T> void qrb_issue(BlockedQrcpJob<T> *job);
+template <typename T> bool qrb_finish(BlockedQrcpJob<T> *job);
+template <typename T> void qrb_end(BlockedQrcpJob<T> *job);
 // short-wide matrices (m <= 256 << n): read-only "lazy" pivoted QR with the explicit m x m factor
 template <typename T> bool wide_lazy_supported(int64_t m, int64_t n);
 template <typename T> void geqp3_wide_lazy(rc_context *c, Mat<T> b, int64_t kmax, int64_t *jpvt, Mat<T> q, Mat<T> r);

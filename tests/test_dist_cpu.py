@@ -82,3 +82,31 @@ def test_pack_unpack_round_trip_is_exact():
         got = batch.unpack_factors(batch.pack_factors(fs), 3, 7, 10, 3)
         for (c, z, i), (c2, z2, i2) in zip(fs, got):
             assert torch.equal(c, c2) and torch.equal(z, z2) and torch.equal(i, i2)
+
+
+def test_c_abi_partition_and_packed_size_agree_with_the_python_mirror():
+    """rc_batch_shard_range / rc_batch_packed_bytes (pure host arithmetic of the C ABI) against batch.shard_range /
+    batch.packed_bytes, including sizes whose factor block is not a multiple of 8 bytes."""
+    import ctypes
+
+    from rusty_compression_amd import _lib
+
+    lib = _lib.lib()
+    lib.rc_batch_packed_bytes.restype = ctypes.c_size_t
+    for n_items in (64, 10, 3, 0):
+        for world in (1, 2, 3, 8):
+            for r in range(world):
+                s, c = ctypes.c_int64(-1), ctypes.c_int64(-1)
+                assert lib.rc_batch_shard_range(ctypes.c_int64(n_items), world, r, ctypes.byref(s), ctypes.byref(c)) == 0
+                rng = batch.shard_range(n_items, world, r)
+                assert (s.value, c.value) == (rng.start, len(rng))
+    s, c = ctypes.c_int64(), ctypes.c_int64()
+    assert lib.rc_batch_shard_range(ctypes.c_int64(5), 2, 2, ctypes.byref(s), ctypes.byref(c)) == _lib.RC_INVALID_ARGUMENT
+    for (m, n, k, es) in ((4096, 4096, 64, 4), (7, 10, 3, 4), (7, 10, 3, 8), (5, 3, 1, 4), (1, 1, 1, 4)):
+        assert lib.rc_batch_packed_bytes(ctypes.c_int64(m), ctypes.c_int64(n), ctypes.c_int64(k), ctypes.c_int32(es)) == batch.packed_bytes(m, n, k, es)
+    # the packed layout: C | Z | pad | col_ind, read back through unpack_factors
+    c_, z_, i_ = torch.arange(15, dtype=torch.float32).reshape(5, 3), torch.arange(9, dtype=torch.float32).reshape(3, 3) + 100, torch.tensor([2, 0, 1])
+    buf = batch.pack_factors([(c_[:, :1].contiguous(), z_[:1].contiguous(), i_)])
+    assert buf.numel() == batch.packed_bytes(5, 3, 1, 4) and buf.numel() % 8 == 0
+    (c2, z2, i2), = batch.unpack_factors(buf, 1, 5, 3, 1, torch.float32)
+    assert torch.equal(c2, c_[:, :1]) and torch.equal(z2, z_[:1]) and torch.equal(i2, i_)

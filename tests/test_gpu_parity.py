@@ -940,7 +940,9 @@ def test_blocked_qrcp_degenerate_inputs(dtype):
     q, r, ind = (npy(t) for t in rc.pivoted_qr(b))
     oq, orr, oind = o.pivoted_qr(b)
     ns = stable_prefix(orr, dtype)
-    assert ns <= 90 and np.array_equal(ind[:ns], oind[:ns])
+    # a column and its copy tie exactly here, while the BLAS kernels behind LAPACK may round the two differently (their
+    # position inside a SIMD group differs): the pivots are compared as "a column or its copy"
+    assert ns <= 90 and np.array_equal(ind[:ns] % 80, oind[:ns] % 80)
     assert rel(q @ r, b[:, ind]) <= (1e-12 if f64 else 1e-5)
     # zero matrix
     z = np.zeros((200, 300), dtype=dtype)
@@ -953,6 +955,24 @@ def test_blocked_qrcp_degenerate_inputs(dtype):
     ns = stable_prefix(orr, dtype)
     assert 38 <= ns <= 42 and np.array_equal(ind[:ns], oind[:ns])
     assert rel(q @ r, x[:, ind]) <= (1e-12 if f64 else 2e-5) and np.abs(q.T @ q - np.eye(400)).max() <= (1e-12 if f64 else 2e-5)
+
+
+def test_rccl_self_gather_of_the_packed_factors():
+    """rc_comm_* on one GPU (world 1): the packed buffer of a small batch goes through the library's RCCL gather unchanged.
+    (The multi-rank layout logic is covered on the CPU: tests/test_dist_cpu.py.)"""
+    from rusty_compression_amd import batch
+
+    mats = [rc.random_gaussian((512, 384), rc.Rng(900 + i), torch.float32) for i in range(3)]
+    packed = batch.batch_column_id_packed(mats, 24, lanes=2)
+    comm = batch.Comm(1, 0, batch.Comm.unique_id())
+    try:
+        got = comm.gather(packed, 0)
+    finally:
+        comm.close()
+    assert got is not None and torch.equal(got, packed)
+    for (c, z, ind), a in zip(batch.unpack_factors(got, 3, 512, 384, 24), mats):
+        c1, z1, i1 = batch.column_id_rank(a, 24)
+        assert torch.equal(ind, i1) and torch.equal(c, c1) and torch.equal(z, z1)
 
 
 def _decaying_matrix(n, sigma_min, dtype, seed):
