@@ -40,6 +40,7 @@
 #include "rc_device.hpp"
 
 #include <cstdlib>
+#include <vector>
 
 namespace rc {
 
@@ -197,17 +198,19 @@ __global__ __launch_bounds__(1024) void k_qrb_select(int n, int j0, int cwant, c
 }
 
 // ---------------------------------------------------------------------------
-// Per-step kernels.  Both are multi-workgroup and free of serial single-CU passes; the few scalar decisions of a step
-// (pivot, stop tests, ?larfg) are evaluated REDUNDANTLY by every workgroup from the same inputs in the same order, so all
-// workgroups agree bit for bit, and only workgroup 0 writes the shared bookkeeping.  Data that one kernel both reads and
-// replaces is double buffered (candidate norms / positions) or kept out of place (the updated pivot column, the rows of
-// R of the candidates), so no workgroup can observe another one's writes of the same launch.
+// Per-step kernels.  Both are multi-workgroup and free of serial single-CU passes.  A step is a chain of dependent
+// global-memory round trips (~1 us each across XCDs), so each kernel is organised as two rounds of independent loads.
+// The few scalar decisions of a step (pivot, stop tests, ?larfg, auxv) are evaluated REDUNDANTLY by every workgroup
+// from the same inputs in the same order -- all workgroups agree bit for bit -- and only workgroup 0 writes the shared
+// bookkeeping; what one launch both reads and replaces is double buffered (candidate positions) or kept out of place
+// (the updated pivot column in xbuf, the candidates' rows of R in Rrow).
 //
-//   step A(k): finish step k-1 for every candidate (F(c, k-1), its entry of row rk-1 of R, norm down-date), pick the
-//              pivot of step k, stop tests, bring the pivot column up to date (row slabs over the workgroups)
-//   step C(k): ?larfg from the slab partial sums, dot products of v_k with every candidate and with the panel's earlier
-//              reflectors (one wave per column), v_k stored
-// A panel of nbp steps is A(0) C(0) ... A(nbp-1) C(nbp-1) A(nbp, final).
+//   step A(k): pivot = first maximum of the candidates' norms, stop tests, "swap"; the pivot column is brought up to
+//              date by row slabs (one per workgroup): x = A(rk:m, c) - V(rk:m, 0:k) F(c, 0:k)^T, with the slab's share
+//              of ||x||^2 and of V^T x
+//   step C(k): one workgroup per unpivoted candidate: ?larfg and auxv from the slab sums, g = A(rk:m, j)^T v, then the
+//              candidate finishes its own step: F(j, k), its entry of row rk of R, the norm down-date
+// A panel of nbp steps is A(0) C(0) ... A(nbp-1) C(nbp-1).
 // ---------------------------------------------------------------------------
 template <typename T>
 struct QrbPanel {
@@ -215,20 +218,17 @@ struct QrbPanel {
     int *pos;             // n: position of physical column (workgroup 0 of step A is the only writer)
     const int *cand;      // candidate -> physical column
     int *cpos[2];         // candidate positions, double buffered by step parity
-    T *cvn[2];            // candidate partial norms (vn1), double buffered
+    T *cvn;               // candidate partial norms (vn1); each entry has one writer (its workgroup in step C)
     const T *vn2;         // n: last exactly computed norm per physical column
     T *Fm;                // n x kNB, row per physical column
-    T *G;                 // raw dot products of the current step, per candidate
-    T *gv;                // kNB: dot products with the panel's earlier reflectors
     T *Rrow;              // kNB x ncap: row j0 + kk of R for the candidates (scattered into the matrix at panel end)
     int64_t ncap;
-    T *xbuf;              // m: the pivot column brought up to date (rows rk .. m-1 at offset 0)
-    T *pss;               // per-slab partial sums of squares + [64] = alpha
+    T *xbuf;              // m (+ pad): the pivot column brought up to date, rows rk .. m-1 at offset (rk mod 16 bytes)
+    T *pss;               // [g] slab sums of squares, [64] = alpha, [128 + g * kNB + t] slab sums of V_t^T x
     int *flag;            // n: norm lost its accuracy, recompute after the block update
     QrbState *st;
     const T *tsc;         // [0] = tau threshold
     T *tau;
-    T *auxv;              // kNB (kept for the panel-end kernels)
     T *Tm;                // kNB x kNB
 };
 
@@ -244,59 +244,28 @@ __device__ inline bool qrb_downdate(T a, T &vn, T vnb) {  // ?laqps norm down-da
     return false;
 }
 
-// F row of a candidate in registers (16-byte loads, all in flight together)
 template <typename T>
-struct QrbRow {
-    static constexpr int VL = 16 / sizeof(T);
-    typedef T vecT __attribute__((ext_vector_type(VL)));
-    vecT f[kNB / VL];
-    __device__ inline void load(const T *frow) {
-        const vecT *fv = reinterpret_cast<const vecT *>(frow);
-#pragma unroll
-        for (int q = 0; q < kNB / VL; ++q) f[q] = fv[q];
-    }
-    // e = F(c, :) . aux, sr = vrow . F(c, :) over all 32 entries (entries beyond the current step meet zeros in aux / vrow;
-    // the F matrix is zero-initialised, so they are finite)
-    __device__ inline void dots(const T *aux, const T *vrow, T &e, T &sr) const {
-        e = 0;
-        sr = 0;
-#pragma unroll
-        for (int q = 0; q < kNB / VL; ++q)
-#pragma unroll
-            for (int u = 0; u < VL; ++u) {
-                e = fma(f[q][u], aux[q * VL + u], e);
-                sr = fma(vrow[q * VL + u], f[q][u], sr);
-            }
-    }
-    __device__ inline void store_lds(T *dst) const {
-#pragma unroll
-        for (int q = 0; q < kNB / VL; ++q)
-#pragma unroll
-            for (int u = 0; u < VL; ++u) dst[q * VL + u] = f[q][u];
-    }
-};
-
-// Step A.  The kernel is a chain of dependent global-memory round trips (~0.7 us each), so loads are grouped into three
-// rounds: (1) panel state + this thread's candidates, (2) their F rows / dot products / matrix entries, (3) the pivot
-// column slab with all of the panel's reflector rows.
-template <typename T>
-__global__ __launch_bounds__(256) void k_qrb_step_a(Mat<T> w, int j0, int k, int final_only, QrbPanel<T> P) {
-    __shared__ T shaux[kNB], shvrow[kNB], shF[kNB];
+__global__ __launch_bounds__(256) void k_qrb_step_a(Mat<T> w, int j0, int k, QrbPanel<T> P) {
+    __shared__ T shF[kNB];
     __shared__ int shpiv[kNB];
     __shared__ T shv[4];
-    __shared__ int shp[4], shi[4], shc[4], shlost[4];
-    __shared__ T sh4[4];
+    __shared__ int shp[4], shi[4], shc[4];
+    __shared__ T shpart[4 * (kNB + 1)];
     QrbState *st = P.st;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const bool wg0 = blockIdx.x == 0;
-    const int rk = j0 + k, rkp = rk - 1;
+    const int rk = j0 + k;
     const int cur = k & 1, nxt = cur ^ 1;
     const int64_t m = w.rows;
-    const int kp = k - 1;  // the step being finished
     const int *cposc = P.cpos[cur];
-    const T *cvnc = P.cvn[cur];
-    // ---- round 1 ----------------------------------------------------------------------------------------------------
-    constexpr int NPF = 2;  // candidates per thread fetched ahead (512 per workgroup); further ones are fetched in the loop
+    // ---- round 1: panel state, every candidate's norm and position ------------------------------------------------------
+    const int stopped = st->stopped;
+    const int ncand = st->ncand;
+    const int have_noncand = st->have_noncand;
+    const int lsticc = st->lsticc;
+    const T lim = P.tsc[0] * ((T)1 + (T)4 * NumB<T>::tol3z());
+    if (tid < kNB) shpiv[tid] = (tid < k) ? st->piv[tid] : 0;
+    constexpr int NPF = 4;
     int pf_p[NPF], pf_c[NPF];
     T pf_vn[NPF];
 #pragma unroll
@@ -304,100 +273,25 @@ __global__ __launch_bounds__(256) void k_qrb_step_a(Mat<T> w, int j0, int k, int
         const int ci = tid + 256 * e;
         const bool ok = ci < (int)P.ncap;
         pf_p[e] = ok ? cposc[ci] : -1;
-        pf_vn[e] = ok ? cvnc[ci] : (T)0;
+        pf_vn[e] = ok ? P.cvn[ci] : (T)0;
         pf_c[e] = ok ? P.cand[ci] : 0;
     }
-    const int stopped = st->stopped;
-    const int ncand = st->ncand;
-    const int have_noncand = st->have_noncand;
-    const T lim = P.tsc[0] * ((T)1 + (T)4 * NumB<T>::tol3z());
-    const T tkp = k > 0 ? P.tau[rkp] : (T)0;
-    int mypiv = 0;
-    T mygv = 0;
-    if (tid < kNB && k > 0) {
-        mypiv = st->piv[tid < k ? tid : 0];
-        mygv = tid < kp ? P.gv[tid] : (T)0;
-    }
     if (stopped) return;
-    // ---- round 2: F rows and the per-candidate scalars; reflector entries of row rk-1 ------------------------------------
-    QrbRow<T> row[NPF];
-    T pf_g[NPF], pf_w[NPF], pf_v2[NPF];
-    bool act[NPF];
-#pragma unroll
-    for (int e = 0; e < NPF; ++e) {
-        const int ci = tid + 256 * e;
-        act[e] = k > 0 && ci < ncand && pf_p[e] > rkp;  // unpivoted while step k-1 ran
-        pf_g[e] = pf_w[e] = pf_v2[e] = 0;
-        if (act[e]) {
-            row[e].load(P.Fm + (int64_t)pf_c[e] * kNB);
-            pf_g[e] = P.G[ci];
-            pf_w[e] = w.p[(int64_t)pf_c[e] * w.cs + rkp];
-            pf_v2[e] = P.vn2[pf_c[e]];
-        }
-    }
-    T trow[kNB];  // workgroup 0, thread r < k-1: row r of the panel's T factor (columns r .. k-2)
-#pragma unroll
-    for (int q = 0; q < kNB; ++q) trow[q] = (wg0 && tid < kp && q >= tid && q < kp) ? P.Tm[tid + q * kNB] : (T)0;
-    if (tid < kNB) {
-        shpiv[tid] = mypiv;
-        shaux[tid] = tid < kp ? -tkp * mygv : (T)0;
-        shvrow[tid] = (k > 0 && tid < kp) ? w.p[(int64_t)mypiv * w.cs + rkp] : (T)0;
-    }
-    __syncthreads();
-    // ---- finish step k-1 for every candidate + arg max for step k ------------------------------------------------------
     T best = (T)-1;
-    int bp = 0x7fffffff, bi = -1, bcol = 0, lost_any = 0;
-    T my_fk[NPF];
+    int bp = 0x7fffffff, bi = -1, bcol = 0;
 #pragma unroll
     for (int e = 0; e < NPF; ++e) {
         const int ci = tid + 256 * e;
-        my_fk[e] = 0;
-        if (ci < ncand) {
-            T vn = pf_vn[e];
-            if (act[e]) {
-                T ee, sr;
-                row[e].dots(shaux, shvrow, ee, sr);
-                const T fk = tkp * pf_g[e] + ee;
-                my_fk[e] = fk;
-                const T a = pf_w[e] - (sr + fk);
-                const bool lost = qrb_downdate(a, vn, pf_v2[e]);
-                if (lost) lost_any = 1;
-                if (wg0) {
-                    P.Fm[(int64_t)pf_c[e] * kNB + kp] = fk;
-                    P.Rrow[(int64_t)kp * P.ncap + ci] = a;
-                    if (lost) P.flag[pf_c[e]] = 1;
-                }
-            }
-            if (wg0) P.cvn[nxt][ci] = vn;
-            if (pf_p[e] >= rk) {
-                const T v = fabs(vn);
-                if (v > best || (v == best && pf_p[e] < bp)) { best = v; bp = pf_p[e]; bi = ci; bcol = pf_c[e]; }
-            }
+        if (ci < ncand && pf_p[e] >= rk) {
+            const T v = fabs(pf_vn[e]);
+            if (v > best || (v == best && pf_p[e] < bp)) { best = v; bp = pf_p[e]; bi = ci; bcol = pf_c[e]; }
         }
     }
-    for (int ci = tid + 256 * NPF; ci < ncand; ci += 256) {  // more than 512 candidates: the same, fetched on the spot
+    for (int ci = tid + 256 * NPF; ci < ncand; ci += 256) {
         const int p = cposc[ci];
-        const int c = P.cand[ci];
-        T vn = cvnc[ci];
-        if (k > 0 && p > rkp) {
-            QrbRow<T> r2;
-            r2.load(P.Fm + (int64_t)c * kNB);
-            T ee, sr;
-            r2.dots(shaux, shvrow, ee, sr);
-            const T fk = tkp * P.G[ci] + ee;
-            const T a = w.p[(int64_t)c * w.cs + rkp] - (sr + fk);
-            const bool lost = qrb_downdate(a, vn, P.vn2[c]);
-            if (lost) lost_any = 1;
-            if (wg0) {
-                P.Fm[(int64_t)c * kNB + kp] = fk;
-                P.Rrow[(int64_t)kp * P.ncap + ci] = a;
-                if (lost) P.flag[c] = 1;
-            }
-        }
-        if (wg0) P.cvn[nxt][ci] = vn;
         if (p >= rk) {
-            const T v = fabs(vn);
-            if (v > best || (v == best && p < bp)) { best = v; bp = p; bi = ci; bcol = c; }
+            const T v = fabs(P.cvn[ci]);
+            if (v > best || (v == best && p < bp)) { best = v; bp = p; bi = ci; bcol = P.cand[ci]; }
         }
     }
     {
@@ -406,39 +300,19 @@ __global__ __launch_bounds__(256) void k_qrb_step_a(Mat<T> w, int j0, int k, int
         pc = wave_min_dpp(pc);
         if (bi >= 0 && best == mx && bp == pc) { shv[wv] = mx; shp[wv] = bp; shi[wv] = bi; shc[wv] = bcol; }
         else if (lane == 0 && pc == 0x7fffffff) { shv[wv] = (T)-1; shp[wv] = 0x7fffffff; shi[wv] = -1; shc[wv] = 0; }
-        int la = lost_any;
-        la |= __shfl_xor(la, 32, 64); la |= __shfl_xor(la, 16, 64); la |= __shfl_xor(la, 8, 64);
-        la |= __shfl_xor(la, 4, 64); la |= __shfl_xor(la, 2, 64); la |= __shfl_xor(la, 1, 64);
-        if (lane == 0) shlost[wv] = la;
     }
     __syncthreads();
     T bb = shv[0];
     int pp = shp[0], ci_s = shi[0], cs = shc[0];
     for (int i = 1; i < 4; ++i)
         if (shi[i] >= 0 && (ci_s < 0 || shv[i] > bb || (shv[i] == bb && shp[i] < pp))) { bb = shv[i]; pp = shp[i]; ci_s = shi[i]; cs = shc[i]; }
-    const int lost_all = shlost[0] | shlost[1] | shlost[2] | shlost[3];
-    // ---- workgroup 0: T column of step k-1, latest norm buffer -------------------------------------------------------
-    if (wg0 && k > 0) {
-        if (tid < kp) P.auxv[tid] = shaux[tid];
-        if (tid <= kp) {
-            T sacc = tkp;
-            if (tid < kp) {
-                sacc = 0;
-#pragma unroll
-                for (int q = 0; q < kNB; ++q) sacc = fma(trow[q], shaux[q], sacc);  // zeros outside tid <= q < k-1
-            }
-            P.Tm[tid + kp * kNB] = sacc;
-        }
-    }
-    if (wg0 && tid == 0) st->pad0 = nxt;  // buffer that holds the norms after step k-1
     // ---- stop tests (identical in every workgroup) -----------------------------------------------------------------------
     int stop = 0, why_tau = 0;
-    if (final_only) stop = 1;
-    else if (lost_all) stop = 1;                    // ?laqps: the panel ends after the step in which a norm lost its accuracy
+    if (lsticc) stop = 1;                           // ?laqps: the panel ends after the step in which a norm lost its accuracy
     else if (ci_s < 0) stop = 1;                    // every candidate has been used
     else if (k > 0 && have_noncand && !(bb > lim)) { stop = 1; why_tau = 1; }
     if (stop) {
-        if (wg0 && tid == 0) { st->stopped = 1; st->kb = k; st->lsticc = lost_all; st->stop_tau = why_tau; }
+        if (wg0 && tid == 0) { st->stopped = 1; st->kb = k; st->stop_tau = why_tau; }
         return;
     }
     // ---- workgroup 0: swap bookkeeping ------------------------------------------------------------------------------------
@@ -461,56 +335,69 @@ __global__ __launch_bounds__(256) void k_qrb_step_a(Mat<T> w, int j0, int k, int
             st->piv[k] = cs;
         }
     }
-    // ---- F row of the pivot column: its owner thread has it in registers ------------------------------------------------------
-    if (tid < kNB) shF[tid] = 0;
-    __syncthreads();
-    if (k > 0) {
-        if (ci_s < 256 * NPF) {
-#pragma unroll
-            for (int e = 0; e < NPF; ++e)
-                if (tid + 256 * e == ci_s) { row[e].store_lds(shF); shF[kp] = my_fk[e]; }
-        } else if (tid == 0) {
-            QrbRow<T> r2;
-            r2.load(P.Fm + (int64_t)cs * kNB);
-            T ee, sr;
-            r2.dots(shaux, shvrow, ee, sr);
-            r2.store_lds(shF);
-            shF[kp] = tkp * P.G[ci_s] + ee;
-        }
-    }
-    __syncthreads();
-    // ---- round 3: pivot column up to date, one row slab per workgroup: x = A(rk:m, c) - V(rk:m, 0:k) F(c, 0:k)^T -----------
+    // ---- round 2: pivot column slab, the panel's reflector rows, F row of the pivot column -----------------------------------
     const int64_t nrows = m - rk;
     const int64_t slab = (nrows + gridDim.x - 1) / gridDim.x;
     const int64_t r0 = (int64_t)blockIdx.x * slab, r1 = min(nrows, r0 + slab);
     const T *wc = w.p + (int64_t)cs * w.cs + rk;
     const int xoff = rk & (16 / (int)sizeof(T) - 1);  // xbuf(r) sits at the same 16-byte phase as row rk + r of a column
     T ss = 0;
-    for (int64_t r = r0 + tid; r < r1; r += 256) {
+    T pv[kNB];  // this thread's share of V_t(rk+1:m)^T x(1:)
+#pragma unroll
+    for (int t = 0; t < kNB; ++t) pv[t] = 0;
+    // the first row of this thread: loads issued together with the F row, before the barrier that publishes it
+    const int64_t rf = r0 + tid;
+    const bool hasf = rf < r1;
+    T xf = hasf ? wc[rf] : (T)0;
+    T vf[kNB];
+#pragma unroll
+    for (int t = 0; t < kNB; ++t) vf[t] = (hasf && t < k) ? w.p[(int64_t)shpiv[t] * w.cs + rk + rf] : (T)0;
+    if (tid < kNB) shF[tid] = tid < k ? P.Fm[(int64_t)cs * kNB + tid] : (T)0;
+    __syncthreads();
+    auto process = [&](int64_t r, T x, const T *vv) {
+#pragma unroll
+        for (int t = 0; t < kNB; ++t) x = fma(-vv[t], shF[t], x);  // shF is zero beyond the step (and vv too)
+        P.xbuf[xoff + r] = x;
+        if (r > 0) {
+            ss = fma(x, x, ss);
+#pragma unroll
+            for (int t = 0; t < kNB; ++t) pv[t] = fma(vv[t], x, pv[t]);
+        } else {
+            P.pss[64] = x;  // alpha
+        }
+    };
+    if (hasf) process(rf, xf, vf);
+    for (int64_t r = rf + 256; r < r1; r += 256) {  // slabs longer than the workgroup
         T x = wc[r];
         T vv[kNB];
 #pragma unroll
         for (int t = 0; t < kNB; ++t) vv[t] = t < k ? w.p[(int64_t)shpiv[t] * w.cs + rk + r] : (T)0;
-#pragma unroll
-        for (int t = 0; t < kNB; ++t) x = fma(-vv[t], shF[t], x);  // shF is zero beyond the step (and vv too)
-        P.xbuf[xoff + r] = x;
-        if (r > 0) ss = fma(x, x, ss);
-        else P.pss[64] = x;  // alpha
+        process(r, x, vv);
     }
+    // slab sums: ||x(1:)||^2 and V_t^T x, fixed order (lanes -> waves -> workgroup)
     ss = wave_sum_dpp(ss);
-    if (lane == 0) sh4[wv] = ss;
+    if (lane == 0) shpart[wv * (kNB + 1) + kNB] = ss;
+#pragma unroll
+    for (int t = 0; t < kNB; ++t) {
+        if (t < k) {
+            const T s2 = wave_sum_dpp(pv[t]);
+            if (lane == 0) shpart[wv * (kNB + 1) + t] = s2;
+        }
+    }
     __syncthreads();
-    if (tid == 0) P.pss[blockIdx.x] = (sh4[0] + sh4[1]) + (sh4[2] + sh4[3]);
+    if (tid == 0) P.pss[blockIdx.x] = (shpart[kNB] + shpart[(kNB + 1) + kNB]) + (shpart[2 * (kNB + 1) + kNB] + shpart[3 * (kNB + 1) + kNB]);
+    if (tid < k) P.pss[128 + blockIdx.x * kNB + tid] = (shpart[tid] + shpart[(kNB + 1) + tid]) + (shpart[2 * (kNB + 1) + tid] + shpart[3 * (kNB + 1) + tid]);
 }
 
-// Step C.  Two load rounds: (1) panel state, slab partial sums and this workgroup's target, (2) the target column and
-// the up-to-date pivot column (16-byte loads, issued before ?larfg is evaluated from round 1's data).
+// Step C: one workgroup per candidate.
 template <typename T>
 __global__ __launch_bounds__(256) void k_qrb_step_c(Mat<T> w, int j0, int k, int nslab, int vec_ok, QrbPanel<T> P) {
     constexpr int VL = 16 / sizeof(T);
     typedef T vecT __attribute__((ext_vector_type(VL)));
     __shared__ T shs[4];
     __shared__ T shw[4];
+    __shared__ T shaux[kNB], shvrow[kNB];
+    __shared__ T shpg[8 * kNB];
     QrbState *st = P.st;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int rk = j0 + k;
@@ -523,8 +410,24 @@ __global__ __launch_bounds__(256) void k_qrb_step_c(Mat<T> w, int j0, int k, int
     const int cpiv = st->piv[k];
     const T part = (tid < nslab && tid < 64) ? P.pss[tid] : (T)0;
     const T alpha = P.pss[64];
+    // slab sums of V_t^T x: thread (t = tid & 31, group = tid >> 5) fetches 8 of the (at most 64) slabs, all loads independent
+    T pgq = 0;
+    {
+        const int t = tid & (kNB - 1), gq = tid >> 5;
+        T part8[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int g = gq * 8 + u;
+            part8[u] = (t < k && g < nslab) ? P.pss[128 + g * kNB + t] : (T)0;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) pgq += part8[u];
+    }
+    int mypiv = 0;
+    if (tid < k) mypiv = st->piv[tid];
     int pf_c = 0, pf_p = 0;
-    if ((int)blockIdx.x < (int)P.ncap) { pf_c = P.cand[blockIdx.x]; pf_p = P.cpos[nxt][blockIdx.x]; }
+    T pf_vn = 0;
+    if ((int)blockIdx.x < (int)P.ncap) { pf_c = P.cand[blockIdx.x]; pf_p = P.cpos[nxt][blockIdx.x]; pf_vn = P.cvn[blockIdx.x]; }
     if (stopped) return;
     const T *xb = P.xbuf + xoff;
     T *vcol = w.p + (int64_t)cpiv * w.cs + rk;
@@ -532,9 +435,12 @@ __global__ __launch_bounds__(256) void k_qrb_step_c(Mat<T> w, int j0, int k, int
     const int peel = vec_ok ? (int)min((int64_t)((VL - xoff) & (VL - 1)), nrows) : 0;
     const int64_t nv = vec_ok ? (nrows - peel) / VL : 0;
     const int64_t tail0 = peel + nv * VL;
+    // row rk of the panel's reflectors (needed for gv and for the row update)
+    const T myvrow = tid < k ? w.p[(int64_t)mypiv * w.cs + rk] : (T)0;
     T tk = 0, beta = 0, scal = 0;
     bool have = false;
-    auto larfg = [&]() {  // ?larfg from the slab partial sums (every workgroup, identical); uniform call sites only
+    auto larfg = [&]() {  // ?larfg and auxv from the slab sums (every workgroup, identical); uniform call sites only
+        shpg[tid] = pgq;  // [group][t]
         if (tid < 64) {
             const T s = wave_sum_dpp(part);
             if (tid == 0) {
@@ -550,19 +456,27 @@ __global__ __launch_bounds__(256) void k_qrb_step_c(Mat<T> w, int j0, int k, int
         }
         __syncthreads();
         tk = shs[0]; beta = shs[1]; scal = shs[2];
+        if (tid < kNB) {
+            T pg = 0;  // V_t(rk+1:m)^T x(1:), the eight slab groups in fixed order
+#pragma unroll
+            for (int q = 0; q < 8; ++q) pg += shpg[q * kNB + tid];
+            // V_t(rk:m)^T v with v(rk) = 1, v(rk+1:) = x(1:) * scal
+            const T gvt = tid < k ? myvrow + scal * pg : (T)0;
+            shaux[tid] = tid < k ? -tk * gvt : (T)0;
+            shvrow[tid] = myvrow;
+        }
+        __syncthreads();
         have = true;
     };
-    // ---- one workgroup per target column: the candidates, then the panel's earlier reflectors -------------------------------
-    for (int tg = blockIdx.x; tg < ncand + k; tg += gridDim.x) {
-        const T *col;
-        if (tg < ncand) {
-            const int p = tg == (int)blockIdx.x ? pf_p : P.cpos[nxt][tg];
-            if (p <= rk) continue;  // pivoted (uniform over the workgroup, before any barrier)
-            col = w.p + (int64_t)(tg == (int)blockIdx.x ? pf_c : P.cand[tg]) * w.cs + rk;
-        } else {
-            col = w.p + (int64_t)st->piv[tg - ncand] * w.cs + rk;
-        }
-        // round 2: the first four vectors per thread of the column and of x (4096 rows of f32 / 2048 of f64 per workgroup)
+    for (int tg = blockIdx.x; tg < ncand; tg += gridDim.x) {
+        const bool mine = tg == (int)blockIdx.x;
+        const int p = mine ? pf_p : P.cpos[nxt][tg];
+        if (p <= rk) continue;  // pivoted (uniform over the workgroup, before any barrier)
+        const int c = mine ? pf_c : P.cand[tg];
+        T vn = mine ? pf_vn : P.cvn[tg];
+        const T *col = w.p + (int64_t)c * w.cs + rk;
+        // round 2: the first four vectors per thread of the column and of x (4096 rows of f32 / 2048 of f64 per workgroup),
+        // and what thread 0 needs to finish the candidate's step
         const vecT *cv = reinterpret_cast<const vecT *>(col + peel);
         const vecT *xv = reinterpret_cast<const vecT *>(xb + peel);
         vecT cq[4], xq[4];
@@ -573,9 +487,11 @@ __global__ __launch_bounds__(256) void k_qrb_step_c(Mat<T> w, int j0, int k, int
             cq[q] = ok ? cv[v] : vecT{};
             xq[q] = ok ? xv[v] : vecT{};
         }
-        const T c_diag = tid == 0 ? col[0] : (T)0;  // unit diagonal of the reflector
+        const T c_diag = tid == 0 ? col[0] : (T)0;  // unit diagonal of the reflector; also the entry of row rk to update
         T c_head = 0, x_head = 0;
         if (tid >= 1 && tid < peel) { c_head = col[tid]; x_head = xb[tid]; }
+        const T ft = (tid < k) ? P.Fm[(int64_t)c * kNB + tid] : (T)0;   // F(c, 0:k)
+        const T vnb = tid == 0 ? P.vn2[c] : (T)0;
         if (!have) larfg();
         T a0 = c_diag, a1 = 0, a2 = 0, a3 = 0;
         if (tk != (T)0) {
@@ -597,17 +513,43 @@ __global__ __launch_bounds__(256) void k_qrb_step_c(Mat<T> w, int j0, int k, int
             }
         }
         T g = wave_sum_dpp((a0 + a1) + (a2 + a3));
+        // e = F(c, 0:k) . auxv, sr = V(rk, 0:k) . F(c, 0:k): lanes t < k of wave 0 (entries beyond k are zero)
+        T e = 0, sr = 0;
+        if (wv == 0) {  // (ft is zero in lanes >= k)
+            e = wave_sum_dpp(ft * shaux[lane & (kNB - 1)]);
+            sr = wave_sum_dpp(shvrow[lane & (kNB - 1)] * ft);
+        }
         __syncthreads();  // shw of the previous target has been read
         if (lane == 0) shw[wv] = g;
         __syncthreads();
         if (tid == 0) {
             g = (shw[0] + shw[1]) + (shw[2] + shw[3]);
-            if (tg < ncand) P.G[tg] = g;
-            else P.gv[tg - ncand] = g;
+            // the candidate finishes its own step: F(c, k), its entry of row rk of R, the norm down-date
+            const T fk = tk * g + e;
+            const T a = c_diag - (sr + fk);
+            P.Fm[(int64_t)c * kNB + k] = fk;
+            P.Rrow[(int64_t)k * P.ncap + tg] = a;
+            if (qrb_downdate(a, vn, vnb)) { P.flag[c] = 1; st->lsticc = 1; }
+            else P.cvn[tg] = vn;
         }
     }
     if (!have) larfg();
-    if (blockIdx.x == 0 && tid == 0) { P.tau[rk] = tk; vcol[0] = beta; }
+    if (blockIdx.x == 0) {
+        if (tid == 0) { P.tau[rk] = tk; vcol[0] = beta; }
+        // column k of the panel's T factor (?larft): T(0:k, k) = T(0:k, 0:k) auxv, T(k, k) = tau_k
+        if (tid <= k && tid < kNB) {
+            T sacc = tk;
+            if (tid < k) {
+                T trow[kNB];
+#pragma unroll
+                for (int q = 0; q < kNB; ++q) trow[q] = (q >= tid && q < k) ? P.Tm[tid + q * kNB] : (T)0;
+                sacc = 0;
+#pragma unroll
+                for (int q = 0; q < kNB; ++q) sacc = fma(trow[q], shaux[q], sacc);
+            }
+            P.Tm[tid + k * kNB] = sacc;
+        }
+    }
     // ---- v stored: rows distributed over the workgroups (nobody reads the column itself in this launch) -----------------------
     {
         const int64_t nr = m - rk - 1;
@@ -624,11 +566,10 @@ __global__ __launch_bounds__(256) void k_qrb_scatter(Mat<T> w, int j0, int kb, Q
     if (ci >= P.st->ncand) return;
     const int c = P.cand[ci];
     const int p = P.pos[c];
-    const int buf = P.st->pad0;
     T *x = w.p + (int64_t)c * w.cs + j0;
     const int lim = min(kb, p - j0);  // rows of R above the column's own diagonal position
     for (int kk = 0; kk < lim; ++kk) x[kk] = P.Rrow[(int64_t)kk * P.ncap + ci];
-    if (p >= j0 + kb) vn1[c] = P.cvn[buf][ci];
+    if (p >= j0 + kb) vn1[c] = P.cvn[ci];
 }
 
 // Vp(i, t) = v_t(j0 + i): zeros above the diagonal, one on it, the reflector below  (rows x kb, column-major)
@@ -636,6 +577,15 @@ template <typename T>
 __global__ __launch_bounds__(256) void k_qrb_build_vp(Mat<T> w, int j0, const QrbState *st, Mat<T> vp) {
     const int t = blockIdx.y;
     const T *col = w.p + (int64_t)st->piv[t] * w.cs + j0;
+    T *out = vp.p + (int64_t)t * vp.cs;
+    for (int64_t i = blockIdx.x * 256 + threadIdx.x; i < vp.rows; i += (int64_t)gridDim.x * 256) out[i] = (i < t) ? (T)0 : (i == t) ? (T)1 : col[i];
+}
+
+// the same from the finished permutation: reflector t of the panel sits in physical column jpvt[j0 + t]
+template <typename T>
+__global__ __launch_bounds__(256) void k_qrb_build_vp_pos(Mat<T> w, int j0, const int64_t *jpvt, Mat<T> vp) {
+    const int t = blockIdx.y;
+    const T *col = w.p + jpvt[j0 + t] * w.cs + j0;
     T *out = vp.p + (int64_t)t * vp.cs;
     for (int64_t i = blockIdx.x * 256 + threadIdx.x; i < vp.rows; i += (int64_t)gridDim.x * 256) out[i] = (i < t) ? (T)0 : (i == t) ? (T)1 : col[i];
 }
@@ -710,11 +660,12 @@ __global__ __launch_bounds__(256) void k_qrb_finish(Mat<T> w, int j0, int kb, co
 }
 
 // exact norms of the flagged columns below row `row0` (?laqps: VN1 = VN2 = ?nrm2 after the block update)
+// all != 0: every unpivoted column (see qrb_finish)
 template <typename T>
-__global__ __launch_bounds__(256) void k_qrb_renorm(Mat<T> w, int row0, const int *pos, int *flag, T *vn1, T *vn2) {
+__global__ __launch_bounds__(256) void k_qrb_renorm(Mat<T> w, int row0, int all, const int *pos, int *flag, T *vn1, T *vn2) {
     const int lane = threadIdx.x & 63;
     for (int64_t c = blockIdx.x * 4 + (threadIdx.x >> 6); c < w.cols; c += (int64_t)gridDim.x * 4) {
-        if (!flag[c]) continue;
+        if (!flag[c] && !all) continue;
         T acc = 0;
         if (pos[c] >= row0) {
             const T *col = w.p + c * w.cs;
@@ -757,6 +708,8 @@ struct BlockedQrcpJob {
     Mat<T> vp;
     int vec_ok;
     int nbp = 0;
+    struct PanelRec { int64_t j0; int kb; T *tm; };
+    std::vector<PanelRec> panels;  // finished panels with their T factors (block form-Q)
 };
 
 template <typename T>
@@ -781,12 +734,11 @@ BlockedQrcpJob<T> *qrb_begin(rc_context *c, Mat<T> w, int64_t kmax, int64_t *jpv
     QrbPanel<T> &P = J->P;
     P.jpvt = jpvt; P.pos = J->pos; P.cand = J->cand;
     P.cpos[0] = c->alloc<int>((size_t)n); P.cpos[1] = c->alloc<int>((size_t)n);
-    P.cvn[0] = c->alloc<T>((size_t)n); P.cvn[1] = c->alloc<T>((size_t)n);
+    P.cvn = c->alloc<T>((size_t)n);
     P.vn2 = J->vn2; P.Fm = J->Fm;
-    P.G = c->alloc<T>((size_t)n); P.gv = c->alloc<T>(kNB);
     P.Rrow = c->alloc<T>((size_t)kNB * n); P.ncap = n;
-    P.xbuf = c->alloc<T>((size_t)m + 16); P.pss = c->alloc<T>(80);
-    P.flag = J->flag; P.tsc = J->tsc; P.tau = tau; P.auxv = J->auxv; P.Tm = J->Tm;
+    P.xbuf = c->alloc<T>((size_t)m + 16); P.pss = c->alloc<T>(128 + 64 * kNB);
+    P.flag = J->flag; P.tsc = J->tsc; P.tau = tau; P.Tm = J->Tm;
     J->st = reinterpret_cast<QrbState *>(c->alloc_bytes(sizeof(QrbState)));
     P.st = J->st;
     J->vp = colmajor(c->alloc<T>((size_t)even_ld(m) * kNB), m, kNB, even_ld(m));
@@ -799,7 +751,8 @@ BlockedQrcpJob<T> *qrb_begin(rc_context *c, Mat<T> w, int64_t kmax, int64_t *jpv
         c->pinned_size = 1 << 16;
     }
     J->host_st = reinterpret_cast<QrbState *>(c->pinned);
-    RC_HIP(hipMemsetAsync(J->Fm, 0, (size_t)n * kNB * sizeof(T), c->stream));  // step A reads whole F rows: keep them finite
+    RC_HIP(hipMemsetAsync(J->Fm, 0, (size_t)n * kNB * sizeof(T), c->stream));  // whole F rows are read: keep them finite
+    RC_HIP(hipMemsetAsync(J->Tm, 0, (size_t)kNB * kNB * sizeof(T), c->stream));  // strictly lower part of T stays zero (block form-Q multiplies by the full square)
     J->vec_ok = (w.cs % (16 / (int64_t)sizeof(T)) == 0 && reinterpret_cast<uintptr_t>(w.p) % 16 == 0) ? 1 : 0;
     hipLaunchKernelGGL(k_qrb_init<T>, dim3((unsigned)std::min<int64_t>(cdivb(n, 4), 8192)), dim3(256), 0, c->stream, w, jpvt, J->pos, J->vn1, J->vn2, J->flag);
     // candidate budget: about RC_QRCP_CAND_MB of column data (L2-resident across the steps of a panel), at least 4 NB columns
@@ -810,24 +763,60 @@ BlockedQrcpJob<T> *qrb_begin(rc_context *c, Mat<T> w, int64_t kmax, int64_t *jpv
 }
 
 template <typename T>
+static void qrb_issue_launches(BlockedQrcpJob<T> *J, int nbp, int64_t cw, unsigned grid_a, unsigned grid_c) {
+    rc_context *c = J->c;
+    const int64_t n = J->n, j0 = J->j0;
+    hipLaunchKernelGGL(k_qrb_select<T>, dim3(1), dim3(1024), 0, c->stream, (int)n, (int)j0, (int)cw, J->pos, J->vn1, J->cand, J->is_cand, J->st, J->tsc, J->P.cpos[0],
+                       J->P.cvn);
+    for (int k = 0; k < nbp; ++k) {
+        hipLaunchKernelGGL(k_qrb_step_a<T>, dim3(grid_a), dim3(256), 0, c->stream, J->w, (int)j0, k, J->P);
+        hipLaunchKernelGGL(k_qrb_step_c<T>, dim3(grid_c), dim3(256), 0, c->stream, J->w, (int)j0, k, (int)grid_a, J->vec_ok, J->P);
+    }
+    RC_HIP(hipMemcpyAsync(J->host_st, J->st, sizeof(QrbState), hipMemcpyDeviceToHost, c->stream));
+}
+
+template <typename T>
 void qrb_issue(BlockedQrcpJob<T> *J) {
     rc_context *c = J->c;
     const int64_t m = J->m, n = J->n, j0 = J->j0;
     const int nbp = (int)std::min<int64_t>(kNB, J->kmax - j0);
     J->nbp = nbp;
     const int64_t cw = std::min<int64_t>(J->cwant, n - j0);
-    hipLaunchKernelGGL(k_qrb_select<T>, dim3(1), dim3(1024), 0, c->stream, (int)n, (int)j0, (int)cw, J->pos, J->vn1, J->cand, J->is_cand, J->st, J->tsc, J->P.cpos[0],
-                       J->P.cvn[0]);
-    // step A: every workgroup re-evaluates the per-candidate bookkeeping, so few workgroups when the candidates are many
+    // step A: one row slab of the pivot column per workgroup (every workgroup scans all candidate norms: few workgroups
+    // when the candidates are many); step C: one workgroup per candidate
     const int64_t cbound = std::min<int64_t>(n - j0, 2 * cw);
-    const unsigned grid_a = (unsigned)std::max<int64_t>(4, std::min<int64_t>(std::min<int64_t>(64, cdivb(m - j0, 64)), 32768 / std::max<int64_t>(cbound, 1)));
-    const unsigned grid_c = (unsigned)std::max<int64_t>(1, std::min<int64_t>(cbound + kNB, 4096));
-    for (int k = 0; k < nbp; ++k) {
-        hipLaunchKernelGGL(k_qrb_step_a<T>, dim3(grid_a), dim3(256), 0, c->stream, J->w, (int)j0, k, 0, J->P);
-        hipLaunchKernelGGL(k_qrb_step_c<T>, dim3(grid_c), dim3(256), 0, c->stream, J->w, (int)j0, k, (int)grid_a, J->vec_ok, J->P);
+    const unsigned grid_a = (unsigned)std::max<int64_t>(4, std::min<int64_t>(std::min<int64_t>(64, cdivb(m - j0, 64)), 65536 / std::max<int64_t>(cbound, 1)));
+    const unsigned grid_c = (unsigned)std::max<int64_t>(1, std::min<int64_t>(cbound, 4096));
+    // A panel is ~65 dependent launches at ~3.5 us of host time each: replay them from a hipGraph, cached on the context
+    // under everything the launches bake in (the arena hands out the same addresses for the same call sequence, so a
+    // host that compresses many same-shaped matrices replays).  Opt-in (RC_QRCP_GRAPH=1): measured on MI355X the replay does not
+    // beat eager issue -- with 8 matrices in flight the path is bound by the command processor (~3-4 us per kernel over all
+    // streams), not by the host: 1085 matrices/s replayed vs 1207 eager for 8 x (4096 x 4096 f32, k = 64).
+    static const int use_graph = env_int_b("RC_QRCP_GRAPH", 0);
+    // (only for factorizations of a few panels -- the truncated rank-k case: a long one has a different (j0, candidates)
+    // at every panel and would capture each graph for a single use)
+    if (!use_graph || c->prof_on || J->kmax > 4 * kNB) { qrb_issue_launches(J, nbp, cw, grid_a, grid_c); return; }
+    const std::vector<uint64_t> key = {(uint64_t)(uintptr_t)J->w.p, (uint64_t)J->w.cs, (uint64_t)m, (uint64_t)n, (uint64_t)(uintptr_t)J->jpvt, (uint64_t)(uintptr_t)J->tau,
+                                       (uint64_t)(uintptr_t)J->st, (uint64_t)(uintptr_t)J->host_st, (uint64_t)j0, (uint64_t)nbp, (uint64_t)cw, (uint64_t)sizeof(T),
+                                       (uint64_t)(uintptr_t)c->stream};
+    auto it = c->qrb_graphs.find(key);
+    if (it == c->qrb_graphs.end()) {
+        if (c->qrb_graphs.size() >= 64) {  // bounded: a host cycling through many shapes simply re-captures
+            for (auto &kv : c->qrb_graphs) (void)hipGraphExecDestroy(kv.second);
+            c->qrb_graphs.clear();
+        }
+        hipGraph_t graph = nullptr;
+        hipGraphExec_t exec = nullptr;
+        if (hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal) != hipSuccess) { (void)hipGetLastError(); qrb_issue_launches(J, nbp, cw, grid_a, grid_c); return; }
+        bool ok = true;
+        try { qrb_issue_launches(J, nbp, cw, grid_a, grid_c); } catch (const Error &) { ok = false; }
+        if (hipStreamEndCapture(c->stream, &graph) != hipSuccess || !graph) ok = false;
+        if (ok && hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0) != hipSuccess) ok = false;
+        if (graph) (void)hipGraphDestroy(graph);
+        if (!ok) { (void)hipGetLastError(); qrb_issue_launches(J, nbp, cw, grid_a, grid_c); return; }
+        it = c->qrb_graphs.emplace(key, exec).first;
     }
-    hipLaunchKernelGGL(k_qrb_step_a<T>, dim3(1), dim3(256), 0, c->stream, J->w, (int)j0, nbp, 1, J->P);
-    RC_HIP(hipMemcpyAsync(J->host_st, J->st, sizeof(QrbState), hipMemcpyDeviceToHost, c->stream));
+    RC_HIP(hipGraphLaunch(it->second, c->stream));
 }
 
 // to be called after the context's stream has been synchronised since qrb_issue(); true = factorization complete
@@ -836,8 +825,8 @@ bool qrb_finish(BlockedQrcpJob<T> *J) {
     rc_context *c = J->c;
     const QrbState h = *J->host_st;
     const int64_t m = J->m, n = J->n, j0 = J->j0;
-    const int kb = h.kb;  // (the final step A always stops the panel)
-    RC_REQUIRE(h.stopped && kb >= 1 && kb <= J->nbp, RC_PIVOTED_QR_ERROR, "geqp3_blocked: panel at %lld made %d steps", (long long)j0, kb);
+    const int kb = h.stopped ? h.kb : J->nbp;
+    RC_REQUIRE(kb >= 1 && kb <= J->nbp, RC_PIVOTED_QR_ERROR, "geqp3_blocked: panel at %lld made %d steps", (long long)j0, kb);
     const int64_t rows = m - j0;
     const bool last = j0 + kb >= J->kmax;
     Mat<T> w = J->w;
@@ -857,13 +846,54 @@ bool qrb_finish(BlockedQrcpJob<T> *J) {
         //   A(j0+kb:m, :)^T -= F(:, 0:kb) V(kb:, 0:kb)^T
         Mat<T> ft = Mat<T>(J->Fm, n, kb, kNB, 1);
         gemm<T>(c, (T)-1, ft, vpp.sub(kb, rows - kb, 0, kb).t(), (T)1, w.sub(j0 + kb, rows - kb, 0, n).t());
-        hipLaunchKernelGGL(k_qrb_renorm<T>, dim3((unsigned)std::min<int64_t>(cdivb(n, 4), 4096)), dim3(256), 0, c->stream, w, (int)(j0 + kb), J->pos, J->flag, J->vn1,
-                           J->vn2);
+        // ?laqps recomputes the norms it flagged.  When a CANDIDATE lost its accuracy (the panel ended for it) every
+        // unpivoted column is recomputed instead: on matrices with a steadily decaying spectrum all columns drift towards the
+        // accuracy threshold together (vn1 / vn2 shrinks at the same rate everywhere), and recomputing them one flag at a
+        // time would end a panel after every single step for hundreds of steps (which is what LAPACK's own ?geqp3 does there)
+        hipLaunchKernelGGL(k_qrb_renorm<T>, dim3((unsigned)std::min<int64_t>(cdivb(n, 4), 4096)), dim3(256), 0, c->stream, w, (int)(j0 + kb), h.lsticc, J->pos, J->flag,
+                           J->vn1, J->vn2);
     }
     // a panel that the tau test ended early means the candidate set was too small for this spectrum
-    if (h.stop_tau && kb < J->nbp / 2) J->cwant = std::min<int64_t>(n, J->cwant * 2);
+    {   // keep the panel's T factor for the block form-Q
+        T *tsave = c->alloc<T>((size_t)kNB * kNB);
+        RC_HIP(hipMemcpyAsync(tsave, J->Tm, (size_t)kNB * kNB * sizeof(T), hipMemcpyDeviceToDevice, c->stream));
+        J->panels.push_back({j0, kb, tsave});
+    }
+    static const int dbg = env_int_b("RC_QRCP_DEBUG", 0);
+    if (dbg) fprintf(stderr, "qrb panel j0=%lld kb=%d/%d ncand=%d noncand=%d lsticc=%d stop_tau=%d cwant=%lld\n", (long long)j0, kb, J->nbp, h.ncand, h.have_noncand, h.lsticc, h.stop_tau, (long long)J->cwant);
+    if (h.stop_tau && kb < J->nbp) J->cwant = std::min<int64_t>(n, kb < J->nbp / 2 ? J->cwant * 2 : J->cwant * 3 / 2);
     J->j0 += kb;
     return J->j0 >= J->kmax;
+}
+
+// Q(:, 0:kq) = H_0 ... H_{k-1} [I ; 0] from the finished job, panel by panel from the last to the first:
+//   X <- (I - V_p T_p V_p^T) X  on rows j0_p .. m-1, columns j0_p .. kq-1 (the other columns are still unit vectors above row j0_p)
+// = three MFMA GEMMs per panel (?orgqr's blocked form with the T factors the panels already built).  q: m x kq column-major.
+template <typename T>
+void qrb_form_q(BlockedQrcpJob<T> *J, Mat<T> q) {
+    rc_context *c = J->c;
+    RC_REQUIRE(q.rs == 1 && q.rows == J->m, RC_LAYOUT_ERROR, "qrb_form_q: column-major m x kq output required");
+    if (q.empty()) return;
+    ProfScope ps(c, "op:form_q_blocked %lldx%lld panels=%d", (long long)J->m, (long long)q.cols, (int)J->panels.size());
+    ArenaMark mark(c);
+    fill_identity(c, q);
+    const int64_t m = J->m, kq = q.cols;
+    T *w2p = c->alloc<T>((size_t)kNB * even_ld(kq));
+    T *w3p = c->alloc<T>((size_t)kNB * even_ld(kq));
+    for (int pi = (int)J->panels.size() - 1; pi >= 0; --pi) {
+        const auto &pr = J->panels[(size_t)pi];
+        if (pr.j0 >= kq) continue;  // reflectors beyond the requested columns act on zero rows only
+        const int64_t rows = m - pr.j0, ncols = kq - pr.j0;
+        const int kb = pr.kb;
+        Mat<T> vpp = Mat<T>(J->vp.p, rows, kb, 1, J->vp.cs);
+        // the panel's pivot columns: positions j0 .. j0+kb-1 of jpvt (device) -> build V from them
+        hipLaunchKernelGGL(k_qrb_build_vp_pos<T>, dim3((unsigned)std::min<int64_t>(cdivb(rows, 256), 64), (unsigned)kb), dim3(256), 0, c->stream, J->w, (int)pr.j0, J->jpvt, vpp);
+        Mat<T> qs = q.sub(pr.j0, rows, pr.j0, ncols);
+        Mat<T> w2 = rowmajor(w2p, kb, ncols, even_ld(kq)), w3 = rowmajor(w3p, kb, ncols, even_ld(kq));
+        gemm<T>(c, 1, vpp.t(), qs, 0, w2);
+        gemm<T>(c, 1, Mat<T>(pr.tm, kb, kb, 1, kNB), w2, 0, w3);  // T is upper triangular with exact zeros below
+        gemm<T>(c, (T)-1, vpp, w3, (T)1, qs);
+    }
 }
 
 template <typename T>
@@ -872,7 +902,7 @@ void qrb_end(BlockedQrcpJob<T> *J) { delete J; }
 // w: m x n column-major working matrix (overwritten with the ?geqp3 output format: R on and above the
 // diagonal in position order, reflectors below, columns never moved); jpvt: n; tau: kmax
 template <typename T>
-void geqp3_blocked(rc_context *c, Mat<T> w, int64_t kmax, int64_t *jpvt, T *tau) {
+void geqp3_blocked(rc_context *c, Mat<T> w, int64_t kmax, int64_t *jpvt, T *tau, Mat<T> q_out) {
     if (std::min(kmax, std::min(w.rows, w.cols)) <= 0) return;
     ProfScope ps(c, "op:geqp3_blocked %lldx%lld k=%lld", (long long)w.rows, (long long)w.cols, (long long)kmax);
     ArenaMark mark(c);
@@ -883,12 +913,14 @@ void geqp3_blocked(rc_context *c, Mat<T> w, int64_t kmax, int64_t *jpvt, T *tau)
         RC_HIP(hipStreamSynchronize(c->stream));
         if (qrb_finish(J)) break;
     }
+    if (!q_out.empty()) qrb_form_q(J, q_out);
 }
 
 #define RC_INST_JOB(T)                                                                           \
     template BlockedQrcpJob<T> *qrb_begin<T>(rc_context *, Mat<T>, int64_t, int64_t *, T *);     \
     template void qrb_issue<T>(BlockedQrcpJob<T> *);                                             \
     template bool qrb_finish<T>(BlockedQrcpJob<T> *);                                            \
+    template void qrb_form_q<T>(BlockedQrcpJob<T> *, Mat<T>);                                    \
     template void qrb_end<T>(BlockedQrcpJob<T> *);
 RC_INST_JOB(double)
 RC_INST_JOB(float)
@@ -896,7 +928,7 @@ RC_INST_JOB(float)
 
 template bool geqp3_blocked_supported<double>(int64_t, int64_t, int64_t);
 template bool geqp3_blocked_supported<float>(int64_t, int64_t, int64_t);
-template void geqp3_blocked<double>(rc_context *, Mat<double>, int64_t, int64_t *, double *);
-template void geqp3_blocked<float>(rc_context *, Mat<float>, int64_t, int64_t *, float *);
+template void geqp3_blocked<double>(rc_context *, Mat<double>, int64_t, int64_t *, double *, Mat<double>);
+template void geqp3_blocked<float>(rc_context *, Mat<float>, int64_t, int64_t *, float *, Mat<float>);
 
 }  // namespace rc

@@ -150,6 +150,8 @@ void rc_context::release_all() {
     pinned = nullptr;
     if (sync_ev) (void)hipEventDestroy(sync_ev);
     sync_ev = nullptr;
+    for (auto &kv : qrb_graphs) (void)hipGraphExecDestroy(kv.second);
+    qrb_graphs.clear();
 }
 
 namespace {
@@ -275,11 +277,16 @@ void qrcp_core(rc_context *c, Mat<T> w, int64_t k, bool pivot, Mat<T> q, Mat<T> 
     }
     T *tau = c->alloc<T>((size_t)std::max<int64_t>(k, 1));
     if (c->opt_blocked && pivot && !c->capturing && geqp3_blocked_supported<T>(w.rows, n, k)) {
-        geqp3_blocked<T>(c, w, k, ind, tau);
-    } else {
-        T *vn = c->alloc<T>((size_t)std::max<int64_t>(2 * n, 1));
-        geqp3_inplace(c, w, k, pivot, ind, tau, vn);
+        // blocked ?laqps panels; Q comes out of the same job (block reflectors with the panels' T factors)
+        const bool direct = !q.empty() && q.rs == 1 && q.cs >= q.rows;
+        Mat<T> qw = q.empty() ? Mat<T>() : (direct ? q : tmp_colmajor<T>(c, w.rows, q.cols));
+        geqp3_blocked<T>(c, w, k, ind, tau, qw);
+        if (!r.empty()) extract_r(c, w, ind, r);
+        if (!q.empty() && !direct) copy_mat(c, qw, q);
+        return;
     }
+    T *vn = c->alloc<T>((size_t)std::max<int64_t>(2 * n, 1));
+    geqp3_inplace(c, w, k, pivot, ind, tau, vn);
     if (!r.empty()) extract_r(c, w, ind, r);
     if (!q.empty()) {
         if (q.rs == 1 && q.cs >= q.rows) {

@@ -20,6 +20,7 @@
 
 #include <algorithm>
 #include <mutex>
+#include <thread>
 
 using namespace rc;
 
@@ -46,12 +47,13 @@ Mat<T> tmp_cm(rc_context *c, int64_t rows, int64_t cols) {
 
 // column ID from the factorization in the ?geqp3 output format (same steps as column_id_rank in rc_api.hip)
 template <typename T>
-void finish_column_id(rc_context *c, Mat<T> w, int64_t k, const T *tau, int64_t *ind, Mat<T> cm, Mat<T> z) {
+void finish_column_id(rc_context *c, Mat<T> w, int64_t k, const T *tau, int64_t *ind, Mat<T> cm, Mat<T> z, BlockedQrcpJob<T> *job) {
     const int64_t m = w.rows, n = w.cols;
     Mat<T> r = rowmajor(c->alloc<T>((size_t)k * even_ld(n)), k, n, even_ld(n));
     extract_r(c, w, ind, r);
     Mat<T> q = tmp_cm<T>(c, m, k);
-    form_q(c, w, ind, tau, k, q);
+    if (job) qrb_form_q(job, q);
+    else form_q(c, w, ind, tau, k, q);
     // QRTraits::column_id (src/qr.rs:270-309): Z = [I | R11^-1 R12] P^T, C = Q R11
     int64_t *inv = c->alloc<int64_t>((size_t)n);
     invert_perm(c, ind, n, inv);
@@ -94,11 +96,34 @@ void batch_column_id(rc_context *const *ctxs, int nctx, const rc_matrix *mats, i
         ~Cleanup() { for (auto &x : l) if (x.job) { qrb_end(x.job); x.job = nullptr; } }
     } cleanup{lanes};
     auto slot = [&](int idx) { return static_cast<char *>(packed) + (size_t)idx * per; };
+    // RC_BATCH_THREADS=1: one host thread per lane for the issue phases (measured slower than inline issue once the panels
+    // replay from hipGraphs: thread start-up + runtime locks cost more than the launches they overlap)
+    static const bool threaded = [] { const char *e = getenv("RC_BATCH_THREADS"); return e && atoi(e) != 0; }();
+    auto for_lanes = [&](auto &&pred, auto &&body) {
+        std::vector<std::thread> th;
+        std::vector<Error> errs((size_t)nctx, Error{RC_OK, ""});
+        for (int l = 0; l < nctx; ++l) {
+            if (!pred(lanes[(size_t)l])) continue;
+            auto run = [&, l] {
+                try {
+                    DeviceGuardB dg(lanes[(size_t)l].c->device);
+                    body(lanes[(size_t)l]);
+                } catch (const Error &e) { errs[(size_t)l] = e; }
+                catch (const std::exception &e) { errs[(size_t)l] = Error{RC_RUNTIME_ERROR, e.what()}; }
+            };
+            if (threaded) th.emplace_back(run);
+            else run();
+        }
+        for (auto &t : th) t.join();
+        for (auto &e : errs)
+            if (e.code != RC_OK) throw e;
+    };
     auto post = [&](Lane &ln) {
         char *base = slot(ln.idx);
         Mat<T> cm = rowmajor(reinterpret_cast<T *>(base), m, k, k);
         Mat<T> z = rowmajor(reinterpret_cast<T *>(base) + (size_t)m * k, k, n, n);
-        finish_column_id<T>(ln.c, ln.w, k, ln.tau, ln.ind, cm, z);
+        finish_column_id<T>(ln.c, ln.w, k, ln.tau, ln.ind, cm, z, ln.job);
+        RC_HIP(hipMemcpyAsync(base + align8(((size_t)m * k + (size_t)k * n) * sizeof(T)), ln.ind, (size_t)n * sizeof(int64_t), hipMemcpyDeviceToDevice, ln.c->stream));
     };
     for (int base = 0; base < count; base += nctx) {
         int nact = 0;
@@ -110,7 +135,9 @@ void batch_column_id(rc_context *const *ctxs, int nctx, const rc_matrix *mats, i
             ln.c->reset_arena();
             ln.w = tmp_cm<T>(ln.c, m, n);
             ln.tau = ln.c->template alloc<T>((size_t)k);
-            ln.ind = reinterpret_cast<int64_t *>(slot(ln.idx) + align8(((size_t)m * k + (size_t)k * n) * sizeof(T)));
+            // (the permutation is built in a lane-owned buffer whose address repeats from matrix to matrix, so that the
+            // cached panel graphs of the blocked QRCP replay; it is copied into the packed slot at the end)
+            ln.ind = ln.c->template alloc<int64_t>((size_t)n);
             copy_mat(ln.c, from_c<T>(mats[ln.idx]), ln.w);  // the reference's F-order working copy (pivoted_qr.rs:28-29)
             if (ln.c->opt_blocked && geqp3_blocked_supported<T>(m, n, k)) {
                 ln.job = qrb_begin<T>(ln.c, ln.w, k, ln.ind, ln.tau);
@@ -124,24 +151,22 @@ void batch_column_id(rc_context *const *ctxs, int nctx, const rc_matrix *mats, i
             }
         }
         while (nact > 0) {
-            for (auto &ln : lanes)
-                if (ln.active) { DeviceGuardB dg(ln.c->device); qrb_issue(ln.job); }
+            for_lanes([](Lane &ln) { return ln.active; }, [](Lane &ln) { qrb_issue(ln.job); });
             // one wait for all lanes: an event on every stream first (see rc_synchronize_all)
             std::vector<rc_context *> act;
             for (auto &ln : lanes)
                 if (ln.active) act.push_back(ln.c);
             RC_REQUIRE(rc_synchronize_all(act.data(), (int32_t)act.size()) == RC_OK, RC_RUNTIME_ERROR, "batch_column_id: wait failed");
-            for (auto &ln : lanes) {
-                if (!ln.active) continue;
-                DeviceGuardB dg(ln.c->device);
+            for_lanes([](Lane &ln) { return ln.active; }, [&](Lane &ln) {
                 if (qrb_finish(ln.job)) {
+                    ln.active = false;
+                    post(ln);
                     qrb_end(ln.job);
                     ln.job = nullptr;
-                    ln.active = false;
-                    --nact;
-                    post(ln);
                 }
-            }
+            });
+            nact = 0;
+            for (auto &ln : lanes) nact += ln.active ? 1 : 0;
         }
     }
     std::vector<rc_context *> all(ctxs, ctxs + std::min(nctx, count));

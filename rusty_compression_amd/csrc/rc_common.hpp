@@ -109,6 +109,8 @@ struct rc_context {
     void swap_arena();
     int opt_fork = 0;  // 1: rc_rsvd_id runs its two branches side by side (lower latency; measured LOWER throughput with many graphs in flight)
     hipEvent_t sync_ev = nullptr;       // rc_synchronize_all: one completion event per context
+    // blocked QRCP: the ~65 launches of one panel replayed from a cached hipGraph (keyed by every baked-in pointer / size)
+    std::map<std::vector<uint64_t>, hipGraphExec_t> qrb_graphs;
     void *pinned = nullptr;             // small pinned host buffer for scalar read-backs
     size_t pinned_size = 0;
 
@@ -212,12 +214,14 @@ template <typename T> void geqp3_inplace(rc_context *c, Mat<T> w, int64_t kmax, 
 // general shapes (kernels_qrblk.hip): ?laqps panels on a candidate set + one MFMA GEMM block update per panel; same output
 // format as geqp3_inplace; reads one small struct back per panel (not capturable in a hipGraph)
 template <typename T> bool geqp3_blocked_supported(int64_t m, int64_t n, int64_t kmax);
-template <typename T> void geqp3_blocked(rc_context *c, Mat<T> w, int64_t kmax, int64_t *jpvt, T *tau);
+// q_out (m x kq column-major, may be empty): Q formed panel by panel with the T factors the panels built
+template <typename T> void geqp3_blocked(rc_context *c, Mat<T> w, int64_t kmax, int64_t *jpvt, T *tau, Mat<T> q_out);
 // the same factorization as a resumable job (one host wait per panel): begin -> { issue, <stream synchronised>, finish } ... -> end
 template <typename T> struct BlockedQrcpJob;
 template <typename T> BlockedQrcpJob<T> *qrb_begin(rc_context *c, Mat<T> w, int64_t kmax, int64_t *jpvt, T *tau);
 template <typename T> void qrb_issue(BlockedQrcpJob<T> *job);
 template <typename T> bool qrb_finish(BlockedQrcpJob<T> *job);
+template <typename T> void qrb_form_q(BlockedQrcpJob<T> *job, Mat<T> q);  // after completion
 template <typename T> void qrb_end(BlockedQrcpJob<T> *job);
 // short-wide matrices (m <= 256 << n): read-only "lazy" pivoted QR with the explicit m x m factor
 template <typename T> bool wide_lazy_supported(int64_t m, int64_t n);

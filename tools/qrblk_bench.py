@@ -52,6 +52,8 @@ def main():
         q, hist = rc.sample_range_adaptive(mat, 1e-6, 64, rc.Rng(11))
         for blocked in (1, 0):
             ctx.set_option(_lib.RC_OPT_BLOCKED_QRCP, blocked)
+            warm = rc.QR.compute_from_range_estimate(q, mat).column_id().two_sided_id()  # workspace growth, module load, graph capture
+            del warm
             torch.cuda.synchronize()
             t0 = time.perf_counter()
             qr = rc.QR.compute_from_range_estimate(q, mat)
