@@ -73,6 +73,7 @@ def main():
     ap.add_argument("--no-id", action="store_true", help="rSVD only (skip QR-from-range + column ID)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-baseline-reps", type=int, default=2, help="compressions timed on the host (about 5 s each on the GPU box)")
+    ap.add_argument("--no-concurrency-hint", action="store_true", help="leave RC_OPT_CONCURRENCY_HINT at 1 (every GEMM splits K for a lone launch)")
     ap.add_argument("--no-h2d", action="store_true", help="skip the second throughput figure that re-uploads A before every compression")
     ap.add_argument("--lane-events", action="store_true",
                     help="diagnostic: HIP events around every timed step on its lane's stream; start/end offsets go to stderr")
@@ -145,6 +146,8 @@ def main():
             def call(ctx=ctx, a=a, out=out, seed=7 + s):
                 ctx.call("rc_rsvd_id_f64", _lib.mat(a), ctypes.c_int64(k), ctypes.c_int64(p), _lib.mat(None), ctypes.c_uint64(seed), ctypes.byref(out))
 
+            if not args.no_concurrency_hint:
+                ctx.set_option(_lib.RC_OPT_CONCURRENCY_HINT, S)  # S compressions in flight: wide GEMMs stay un-split (no partial slabs)
             call()  # eager warm-up: sizes the workspace arena (required before capture)
             ctx.synchronize()
             graph = ctypes.c_void_p(None)
@@ -199,6 +202,9 @@ def main():
 
     def profile_samples(ln, lib, n):
         out = []
+        # the kernel is timed as a lone launch: with the hint at 1 it splits K to cover the chip (what `roofline` describes);
+        # the captured graphs of the timed region keep the launch shape they were recorded with
+        ln["ctx"].set_option(_lib.RC_OPT_CONCURRENCY_HINT, 1)
         for _ in range(2):  # untimed: lane's buffers back into the TLBs / caches
             ln["call"]()
         ln["ctx"].synchronize()
@@ -217,6 +223,8 @@ def main():
                 one[name.value.decode()] = ms.value / max(calls.value, 1)
             out.append(one)
         lib.rc_profile_enable(ln["ctx"]._h, 0)
+        if not args.no_concurrency_hint:
+            ln["ctx"].set_option(_lib.RC_OPT_CONCURRENCY_HINT, S)
         return out
 
     # ---- warm-up, then K timed steps (a step = one compression on each of the S lanes) ----
@@ -421,6 +429,7 @@ def main():
             "data": "synthetic",
             "config": {"workload": "cfg3: %dx%d f64 dense N(0,1), rank-%d rSVD%s, p=%d (BASELINE.json configs[2])" % (m, n, k, "+ID" if with_id else "", p),
                        "compressions_per_step": S, "compressions_timed": steps_total,
+                       "concurrency_hint": 1 if args.no_concurrency_hint else S,
                        "streams_per_gpu": S, "hipgraph": not args.no_graph, "parallelism": "independent matrices, %d per GPU in flight" % S},
             "gb_per_s": round(value * by / 1e9, 2),
             "tflops_algorithmic": round(value * total_flops / 1e12, 3),

@@ -136,8 +136,13 @@ rc_status rc_graph_destroy(rc_context *ctx, void *graph_exec);
  * the panel restricted to the candidate columns whose norm can still be the maximum (kernels_qrblk.hip): identical pivoting
  * rule and down-dating formulas, about three passes over the trailing matrix per panel instead of two per step.  Reads one
  * small struct back per panel, so it is not used while a hipGraph is being captured.  0 selects the per-step chain. */
+/* RC_OPT_CONCURRENCY_HINT (default 1): how many independent compressions the host keeps in flight on this device (one
+ * context + stream each).  A lone GEMM splits its reduction dimension until every CU has a workgroup; with many
+ * compressions in flight the other streams fill the chip, and un-split products are cheaper (no partial slabs, no
+ * reduction kernel): with a hint >= 8 a product with >= 32 output tiles is not split.  Results are deterministic for a
+ * given hint; different hints differ by summation order only. */
 enum { RC_OPT_TALL_SKINNY_FAST_PATH = 1, RC_OPT_WIDE_LAZY_QRCP = 2, RC_OPT_WIDE_COOP_QRCP = 3, RC_OPT_POWER_ITERATION_FIXED = 4, RC_OPT_FORK_BRANCHES = 5,
-       RC_OPT_BLOCKED_QRCP = 6 };
+       RC_OPT_BLOCKED_QRCP = 6, RC_OPT_CONCURRENCY_HINT = 7 };
 rc_status rc_set_option(rc_context *ctx, int32_t option, int64_t value);
 /* Health word (read and cleared), OR of: 1 non-positive Cholesky pivot, 2 first CholeskyQR pass too far from orthonormal
  * (both: tall-skinny fast path inside a graph, where no fallback is possible), 4 cooperative short-wide QR could not get

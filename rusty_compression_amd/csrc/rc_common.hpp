@@ -123,6 +123,7 @@ struct rc_context {
     int opt_wide_coop = 1;  // short-wide pivoted QR as ONE cooperative register-resident kernel (0: multi-kernel paths)
     int opt_wide_lazy = 1;  // short-wide pivoted QR through the read-only lazy scheme (0: eager Householder chain)
     int opt_blocked = 1;    // general shapes: blocked ?laqps panels + GEMM block update (0: per-step Householder chain)
+    int opt_lanes = 1;      // RC_OPT_CONCURRENCY_HINT: independent compressions the host keeps in flight on this device
     int *health = nullptr;
     int *health_word();
     unsigned *epoch = nullptr;  // launch counter of the fused Jacobi (keys its producer -> consumer records)
