@@ -1,0 +1,243 @@
+// The reference crate's unit tests (rusty-compression v0.1.1) written against the C++ mirror include/rusty_compression.hpp:
+//   src/pivoted_qr.rs:193-317, src/qr.rs:418-616, src/svd.rs:193-321, src/col_interp_decomp.rs:163-242,
+//   src/row_interp_decomp.rs:163-236, src/permutation.rs:187-240.
+// Same test names, same matrices (the reference's generator recipe, seeded), same assertions and tolerances, for every
+// scalar type the mirror is instantiated for.  This is the COMPILED twin of bindings/rust/tests/reference_tests.rs (the
+// Rust crate cannot be built in this repository's container): tests/test_gpu_parity.py builds it and runs it on the GPU box,
+// the CPU suite compiles and links it.  Prints one line per test and exits non-zero if any assertion failed.
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <string>
+#include <vector>
+
+#include "rusty_compression.hpp"
+
+using namespace rusty_compression;
+
+static int failures = 0, tests_run = 0;
+static bool current_ok = true;
+#define CHECK(cond)                                                                   \
+    do {                                                                              \
+        if (!(cond)) { current_ok = false; std::printf("    assertion failed: %s (line %d)\n", #cond, __LINE__); } \
+    } while (0)
+
+template <typename F>
+static void run_test(const std::string &name, F &&body) {
+    current_ok = true;
+    try {
+        body();
+    } catch (const std::exception &e) {
+        current_ok = false;
+        std::printf("    exception: %s\n", e.what());
+    }
+    ++tests_run;
+    if (!current_ok) ++failures;
+    std::printf("test %s ... %s\n", name.c_str(), current_ok ? "ok" : "FAILED");
+}
+
+template <typename T> struct Name;
+template <> struct Name<float> { static const char *get() { return "f32"; } };
+template <> struct Name<double> { static const char *get() { return "f64"; } };
+
+static uint64_t seed_of(const std::string &s) {
+    uint64_t h = 0xcbf29ce484222325ull;
+    for (unsigned char c : s) h = (h ^ c) * 0x100000001b3ull;
+    return h;
+}
+
+// host copies for the element-wise assertions of the reference's tests
+template <typename T>
+struct Host {
+    std::vector<T> d;
+    int64_t rows, cols;
+    T at(int64_t i, int64_t j) const { return d[(size_t)(i * cols + j)]; }
+};
+template <typename T>
+static Host<T> host(const DeviceMatrix<T> &m) { return Host<T>{m.to_host(), m.nrows(), m.ncols()}; }
+static std::vector<int64_t> host_index(const DeviceIndex &ix) { return ix.to_host(); }
+
+template <typename T>
+static double rel_diff_col(const Host<T> &a, int64_t ca, const Host<T> &b, int64_t cb) {  // RelDiff::rel_diff_l2 on columns
+    double d2 = 0, n2 = 0;
+    for (int64_t i = 0; i < a.rows; ++i) {
+        const double x = (double)a.at(i, ca), y = (double)b.at(i, cb);
+        d2 += (x - y) * (x - y);
+        n2 += y * y;
+    }
+    return std::sqrt(d2) / std::sqrt(n2);
+}
+template <typename T>
+static double rel_diff_row(const Host<T> &a, int64_t ra, const Host<T> &b, int64_t rb) {
+    double d2 = 0, n2 = 0;
+    for (int64_t j = 0; j < a.cols; ++j) {
+        const double x = (double)a.at(ra, j), y = (double)b.at(rb, j);
+        d2 += (x - y) * (x - y);
+        n2 += y * y;
+    }
+    return std::sqrt(d2) / std::sqrt(n2);
+}
+
+template <typename T>
+static void group(const Context &ctx, int64_t m, int64_t n, const char *shape) {
+    const std::string suf = std::string(Name<T>::get()) + "_" + shape;
+    const bool f32 = sizeof(T) == 4;
+    auto mat_for = [&](const std::string &test, double smin) { return random_approximate_low_rank_matrix<T>(ctx, m, n, 1.0, smin, seed_of(test)); };
+
+    // ---- src/pivoted_qr.rs:198-246
+    run_test("pivoted_qr_test_" + std::string(shape) + "_" + Name<T>::get(), [&] {
+        auto mat = mat_for("pivoted_qr_test_" + suf, 1E-5);
+        auto qr = QR<T>::compute_from(mat);
+        auto qtq = host(dot(transpose(qr.q), qr.q));
+        for (int64_t i = 0; i < qtq.rows; ++i)
+            for (int64_t j = 0; j < qtq.cols; ++j) CHECK(std::fabs((double)qtq.at(i, j) - (i == j ? 1.0 : 0.0)) < 1E-6);
+        auto prod = host(dot(qr.q, qr.r)), hm = host(mat);
+        auto ind = host_index(qr.ind);
+        for (int64_t c = 0; c < prod.cols; ++c) CHECK(rel_diff_col(prod, c, hm, ind[(size_t)c]) < 1E-6);
+    });
+    // ---- src/pivoted_qr.rs:248-294
+    run_test("pivoted_lq_test_" + std::string(shape) + "_" + Name<T>::get(), [&] {
+        auto mat = mat_for("pivoted_lq_test_" + suf, 1E-5);
+        auto lq = LQ<T>::compute_from(mat);
+        auto qqt = host(dot(lq.q, transpose(lq.q)));
+        for (int64_t i = 0; i < qqt.rows; ++i)
+            for (int64_t j = 0; j < qqt.cols; ++j) CHECK(std::fabs((double)qqt.at(i, j) - (i == j ? 1.0 : 0.0)) < 1E-6);
+        auto prod = host(dot(lq.l, lq.q)), hm = host(mat);
+        auto ind = host_index(lq.ind);
+        for (int64_t r = 0; r < prod.rows; ++r) CHECK(rel_diff_row(prod, r, hm, ind[(size_t)r]) < 1E-6);
+    });
+    // ---- src/qr.rs:427-457
+    run_test("test_qr_compression_by_rank_" + suf, [&] {
+        const int64_t rank = 30;
+        auto mat = mat_for("test_qr_compression_by_rank_" + suf, 1E-10);
+        auto qr = QR<T>::compute_from(mat).compress(CompressionType::RANK(rank));
+        CHECK(qr.q.ncols() == rank);
+        CHECK(qr.r.nrows() == rank);
+        CHECK((double)rel_diff_fro(qr.to_mat(), mat) < 1E-4);
+    });
+    // ---- src/qr.rs:459-489
+    run_test("test_qr_compression_by_tol_" + suf, [&] {
+        const double tol = 1E-4;
+        auto mat = mat_for("test_qr_compression_by_tol_" + suf, 1E-10);
+        auto qr = QR<T>::compute_from(mat).compress(CompressionType::ADAPTIVE(tol));
+        CHECK((double)rel_diff_fro(qr.to_mat(), mat) < 5.0 * tol);
+        CHECK(qr.q.ncols() < std::min(m, n));
+    });
+    // ---- src/qr.rs:491-530
+    run_test("test_col_id_compression_by_tol_" + suf, [&] {
+        const double tol = 1E-4;
+        auto mat = mat_for("test_col_id_compression_by_tol_" + suf, 1E-10);
+        auto qr = QR<T>::compute_from(mat).compress(CompressionType::ADAPTIVE(tol));
+        const int64_t rank = qr.rank();
+        auto cid = qr.column_id();
+        CHECK((double)rel_diff_fro(cid.to_mat(), mat) < 5.0 * tol);
+        auto hm = host(mat), hc = host(cid.c);
+        auto ind = host_index(cid.col_ind);
+        for (int64_t i = 0; i < rank; ++i) CHECK(rel_diff_col(hm, ind[(size_t)i], hc, i) < tol);  // mat.apply_permutation(col_ind, COL)[:, i] vs C[:, i]
+    });
+    // ---- src/qr.rs:532-571
+    run_test("test_row_id_compression_by_tol_" + suf, [&] {
+        const double tol = 1E-4;
+        auto mat = mat_for("test_row_id_compression_by_tol_" + suf, 1E-10);
+        auto lq = LQ<T>::compute_from(mat).compress(CompressionType::ADAPTIVE(tol));
+        const int64_t rank = lq.rank();
+        auto rid = lq.row_id();
+        CHECK((double)rel_diff_fro(rid.to_mat(), mat) < 5.0 * tol);
+        auto hm = host(mat), hr = host(rid.r);
+        auto ind = host_index(rid.row_ind);
+        for (int64_t i = 0; i < rank; ++i) CHECK(rel_diff_row(hm, ind[(size_t)i], hr, i) < tol);
+    });
+    // ---- src/svd.rs:203-227
+    run_test("test_svd_to_qr_" + suf, [&] {
+        auto mat = mat_for("test_svd_to_qr_" + suf, 1E-10);
+        auto svd = SVD<T>::compute_from(mat);
+        auto actual = svd.to_qr().to_mat();
+        CHECK((double)rel_diff_fro(actual, mat) < (f32 ? 1E-5 : 1E-12));
+    });
+    // ---- src/svd.rs:229-259
+    run_test("test_svd_compression_by_rank_" + suf, [&] {
+        const int64_t rank = 20;
+        auto mat = mat_for("test_svd_compression_by_rank_" + suf, 1E-10);
+        auto svd = SVD<T>::compute_from(mat).compress(CompressionType::RANK(rank));
+        CHECK(svd.u.ncols() == rank);
+        CHECK(svd.vt.nrows() == rank);
+        CHECK((double)rel_diff_fro(svd.to_mat(), mat) < 1E-4);
+    });
+    // ---- src/svd.rs:261-287
+    run_test("test_svd_compression_by_tol_" + suf, [&] {
+        const double tol = 1E-4;
+        auto mat = mat_for("test_svd_compression_by_tol_" + suf, 1E-10);
+        auto svd = SVD<T>::compute_from(mat).compress(CompressionType::ADAPTIVE(tol));
+        CHECK((double)rel_diff_fro(svd.to_mat(), mat) < tol);
+    });
+    // ---- src/col_interp_decomp.rs:176-230 and src/row_interp_decomp.rs:176-224
+    auto two_sided_check = [&](const TwoSidedID<T> &ts, const DeviceMatrix<T> &mat, int64_t rank, double tol) {
+        CHECK((double)rel_diff_fro(ts.to_mat(), mat) < 5.0 * tol);
+        CHECK(ts.x.nrows() == ts.x.ncols());
+        CHECK(ts.x.nrows() == rank);
+        auto hm = host(mat), hx = host(ts.x);
+        auto ri = host_index(ts.row_ind), ci = host_index(ts.col_ind);
+        for (int64_t i = 0; i < rank; ++i)
+            for (int64_t j = 0; j < rank; ++j) {
+                const double ref = (double)hm.at(ri[(size_t)i], ci[(size_t)j]);  // mat.apply_permutation(row_ind, ROW).apply_permutation(col_ind, COL)[i, j]
+                CHECK(std::fabs((double)hx.at(i, j) - ref) < 10.0 * tol * std::fabs(ref));
+            }
+    };
+    run_test("test_two_sided_from_col_id_compression_by_tol_" + suf, [&] {
+        const double tol = 1E-4;
+        auto mat = mat_for("test_two_sided_from_col_id_compression_by_tol_" + suf, 1E-10);
+        auto qr = QR<T>::compute_from(mat).compress(CompressionType::ADAPTIVE(tol));
+        two_sided_check(qr.column_id().two_sided_id(), mat, qr.rank(), tol);
+    });
+    run_test("test_two_sided_from_row_id_compression_by_tol_" + suf, [&] {
+        const double tol = (f32 && m < n) ? 5E-4 : 1E-4;  // the reference relaxes f32 thick (src/row_interp_decomp.rs:231)
+        auto mat = mat_for("test_two_sided_from_row_id_compression_by_tol_" + suf, 1E-10);
+        auto lq = LQ<T>::compute_from(mat).compress(CompressionType::ADAPTIVE(tol));
+        two_sided_check(lq.row_id().two_sided_id(), mat, lq.rank(), tol);
+    });
+}
+
+// ---- src/permutation.rs:192-239 (known answers)
+static void permutation_tests(const Context &ctx) {
+    run_test("test_matrix_permutation", [&] {
+        const double m[9] = {1, 2, 3, 4, 5, 6, 7, 8, 9};
+        const int64_t perm[3] = {2, 0, 1};
+        auto mat = DeviceMatrix<double>::from_host(ctx, m, 3, 3);
+        DeviceIndex idx(ctx, 3);
+        idx.from_host(perm);
+        const double want[4][9] = {{3, 1, 2, 6, 4, 5, 9, 7, 8}, {7, 8, 9, 1, 2, 3, 4, 5, 6}, {2, 3, 1, 5, 6, 4, 8, 9, 7}, {4, 5, 6, 7, 8, 9, 1, 2, 3}};
+        const int modes[4] = {RC_PERM_COL, RC_PERM_ROW, RC_PERM_COLINV, RC_PERM_ROWINV};
+        for (int k = 0; k < 4; ++k) {
+            DeviceMatrix<double> out(ctx, 3, 3);
+            ctx.check(rc_apply_permutation_matrix_f64(ctx.raw(), modes[k], mat.view(), idx.data(), 3, out.view()));
+            auto h = out.to_host();
+            for (int e = 0; e < 9; ++e) CHECK(h[(size_t)e] == want[k][e]);
+        }
+    });
+    run_test("test_vector_permutaiton", [&] {
+        const double v[3] = {1, 2, 3};
+        const int64_t perm[3] = {2, 0, 1};
+        auto vec = DeviceMatrix<double>::from_host(ctx, v, 3, 1);
+        DeviceIndex idx(ctx, 3);
+        idx.from_host(perm);
+        const double want[2][3] = {{3, 1, 2}, {2, 3, 1}};
+        const int modes[2] = {RC_VPERM_NOINV, RC_VPERM_INV};
+        for (int k = 0; k < 2; ++k) {
+            DeviceMatrix<double> out(ctx, 3, 1);
+            ctx.check(rc_apply_permutation_vector_f64(ctx.raw(), modes[k], vec.view(), idx.data(), 3, out.view()));
+            auto h = out.to_host();
+            for (int e = 0; e < 3; ++e) CHECK(h[(size_t)e] == want[k][e]);
+        }
+    });
+}
+
+int main() {
+    Context ctx(0);
+    group<double>(ctx, 100, 50, "thin");
+    group<float>(ctx, 100, 50, "thin");
+    group<double>(ctx, 50, 100, "thick");
+    group<float>(ctx, 50, 100, "thick");
+    permutation_tests(ctx);
+    std::printf("%d tests, %d failed\n", tests_run, failures);
+    return failures ? 1 : 0;
+}

@@ -71,15 +71,15 @@ def test_mirror_exposes_the_reference_surface():
             assert hasattr(cls, m), (cls.__name__, m)
 
 
-def build_cpp_mirror_examples(out_dir):
-    """g++ build of tests/cpp/mirror_examples.cpp against include/rusty_compression.hpp and the in-tree library."""
+def build_cpp_mirror_examples(out_dir, source="mirror_examples.cpp"):
+    """g++ build of tests/cpp/<source> against include/rusty_compression.hpp and the in-tree library."""
     import subprocess
 
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    exe = os.path.join(str(out_dir), "mirror_examples")
+    exe = os.path.join(str(out_dir), os.path.splitext(source)[0])
     libdir = os.path.dirname(_lib.LIB_PATH)
     cmd = ["g++", "-std=c++17", "-O1", "-Wall", "-Wextra", "-Werror", "-I" + os.path.join(root, "include"),
-           os.path.join(root, "tests", "cpp", "mirror_examples.cpp"), "-o", exe, "-L" + libdir, "-lrusty_compression_amd",
+           os.path.join(root, "tests", "cpp", source), "-o", exe, "-L" + libdir, "-lrusty_compression_amd",
            "-Wl,-rpath," + libdir, "-Wl,-rpath-link,/opt/rocm/lib"]
     res = subprocess.run(cmd, capture_output=True, text=True, timeout=300)
     assert res.returncode == 0, res.stderr
@@ -89,3 +89,38 @@ def build_cpp_mirror_examples(out_dir):
 def test_cpp_mirror_header_compiles_and_links_against_the_c_abi(tmp_path):
     exe = build_cpp_mirror_examples(tmp_path)
     assert os.path.exists(exe)
+    # the compiled twin of the Rust crate's test ports (bindings/rust/tests/reference_tests.rs)
+    assert os.path.exists(build_cpp_mirror_examples(tmp_path, "reference_tests.cpp"))
+
+
+def test_rust_binding_is_generated_from_the_header_and_covers_the_reference_surface():
+    """bindings/rust cannot be compiled here (no Rust toolchain): what CAN be checked is that src/ffi.rs is the generator's
+    output for the current header (every exported function, every scalar type), that every trait / type the reference
+    re-exports (src/lib.rs:90-102) exists in the crate, and that all 89 reference tests are ported by name."""
+    import re
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    res = subprocess.run([sys.executable, os.path.join(root, "tools", "gen_rust_ffi.py"), "--check"], capture_output=True, text=True)
+    assert res.returncode == 0, res.stdout + res.stderr
+    ffi = open(os.path.join(root, "bindings", "rust", "src", "ffi.rs")).read()
+    assert set(re.findall(r"pub fn (rc_\w+)", ffi)) == set(_lib.declared_symbols())
+    src = "".join(open(os.path.join(root, "bindings", "rust", "src", f)).read() for f in sorted(os.listdir(os.path.join(root, "bindings", "rust", "src"))))
+    for item in ("pub trait QRTraits", "pub trait LQTraits", "pub trait ColumnIDTraits", "pub trait RowIDTraits", "pub trait TwoSidedIDTraits",
+                 "pub trait SVDTraits", "pub trait RandomMatrix", "pub trait RelDiff", "pub trait SampleRange<", "pub trait SampleRangePowerIteration<",
+                 "pub trait AdaptiveSampling<", "pub trait MaxColNorm<", "pub trait Apply<", "pub trait MatVec", "pub trait MatMat", "pub trait ConjMatVec",
+                 "pub trait ConjMatMat", "pub trait ApplyPermutationToMatrix", "pub trait ApplyPermutationToVector", "pub fn invert_permutation_vector",
+                 "pub enum MatrixPermutationMode", "pub enum VectorPermutationMode", "pub enum CompressionType", "pub enum RustyCompressionError",
+                 "pub struct QR<", "pub struct LQ<", "pub struct SVD<", "pub struct ColumnID<", "pub struct RowID<", "pub struct TwoSidedID<"):
+        assert item in src, item
+    tests = open(os.path.join(root, "bindings", "rust", "tests", "reference_tests.rs")).read()
+    names = set(re.findall(r"^\s+((?:test_|pivoted_)\w+): ", tests, flags=re.M)) | set(re.findall(r"fn (test_\w+)\(\)", tests))
+    assert len(names) == 89, len(names)
+    # the C++ twin runs the real-scalar half of them (the mirror header is instantiated for f32 / f64)
+    cpp = open(os.path.join(root, "tests", "cpp", "reference_tests.cpp")).read()
+    for stem in ("pivoted_qr_test_", "pivoted_lq_test_", "test_qr_compression_by_rank_", "test_qr_compression_by_tol_", "test_col_id_compression_by_tol_",
+                 "test_row_id_compression_by_tol_", "test_svd_to_qr_", "test_svd_compression_by_rank_", "test_svd_compression_by_tol_",
+                 "test_two_sided_from_col_id_compression_by_tol_", "test_two_sided_from_row_id_compression_by_tol_", "test_matrix_permutation",
+                 "test_vector_permutaiton"):
+        assert stem in cpp, stem
