@@ -362,6 +362,72 @@ rc_status rc_comm_gather(rc_comm *comm, rc_context *ctx, const void *send, void 
 rc_status rc_comm_destroy(rc_comm *comm);
 const char *rc_comm_last_error_message(const rc_comm *comm);
 
+/* ------------------------------------------------------------- complex scalars (c32 / c64) -- */
+/* The reference instantiates every trait for f32, f64, c32 and c64 (macros at src/qr.rs:408-416, src/pivoted_qr.rs:187-190,
+ * src/svd.rs:188-191, src/random_sampling.rs:123-126, :165-168, :277-280, src/types.rs:198-204).  Complex matrices are
+ * interleaved (re, im) pairs -- the layout of ndarray's Complex<T> and of numpy complex arrays -- described by the same
+ * rc_matrix (strides in complex elements).  Same semantics as the real entry points with A^H wherever they have A^T:
+ * conj_matmat is A^H X (src/types.rs:128-132), Q has orthonormal columns in the complex inner product, singular values
+ * and norms are real (float / double arguments below), R has a real diagonal (?geqp3), permutation indices as before.
+ * rc_gemm_*: trans = 0 none, 1 transpose, 2 conjugate transpose.  rc_random_gaussian_*: element (i, j) takes normals
+ * 2 (offset + i cols + j) (real part) and the next one (imaginary part) of the Philox stream, the order the reference
+ * draws them in (src/random_matrix.rs:136-143).  Not instantiated for complex: the fused rc_rsvd_id_* / rc_batch_* calls
+ * of the measured real hot path; rc_svd_rank_by_tolerance_* (singular values are real: use the f32 / f64 call). */
+typedef struct rc_complex32 { float re, im; } rc_complex32;
+typedef struct rc_complex64 { double re, im; } rc_complex64;
+rc_status rc_random_gaussian_c64(rc_context *ctx, rc_matrix out, uint64_t seed, uint64_t offset);
+rc_status rc_matmat_c64(rc_context *ctx, rc_matrix a, rc_matrix x, rc_matrix y);
+rc_status rc_conj_matmat_c64(rc_context *ctx, rc_matrix a, rc_matrix x, rc_matrix y);
+rc_status rc_gemm_c64(rc_context *ctx, int32_t trans_a, int32_t trans_b, rc_complex64 alpha, rc_matrix a, rc_matrix b, rc_complex64 beta, rc_matrix c);
+rc_status rc_rel_diff_fro_c64(rc_context *ctx, rc_matrix first, rc_matrix second, double *out);
+rc_status rc_apply_permutation_matrix_c64(rc_context *ctx, int32_t mode, rc_matrix in, const int64_t *perm, int64_t perm_len, rc_matrix out);
+rc_status rc_apply_permutation_vector_c64(rc_context *ctx, int32_t mode, rc_matrix in, const int64_t *perm, int64_t perm_len, rc_matrix out);
+rc_status rc_pivoted_qr_c64(rc_context *ctx, rc_matrix a, rc_matrix q, rc_matrix r, int64_t *ind);
+rc_status rc_pivoted_lq_c64(rc_context *ctx, rc_matrix a, rc_matrix l, rc_matrix q, int64_t *ind);
+rc_status rc_compute_svd_c64(rc_context *ctx, rc_matrix a, rc_matrix u, double *s, rc_matrix vt);
+rc_status rc_rank_by_tolerance_c64(rc_context *ctx, rc_matrix tri, double tol, int64_t *rank);
+rc_status rc_qr_to_mat_c64(rc_context *ctx, rc_matrix q, rc_matrix r, const int64_t *ind, rc_matrix out);
+rc_status rc_lq_to_mat_c64(rc_context *ctx, rc_matrix l, rc_matrix q, const int64_t *ind, rc_matrix out);
+rc_status rc_qr_column_id_c64(rc_context *ctx, rc_matrix q, rc_matrix r, const int64_t *ind, rc_matrix c, rc_matrix z);
+rc_status rc_lq_row_id_c64(rc_context *ctx, rc_matrix l, rc_matrix q, const int64_t *ind, rc_matrix x, rc_matrix r_rows);
+rc_status rc_qr_from_range_estimate_c64(rc_context *ctx, rc_matrix range, rc_matrix a, rc_matrix q, rc_matrix r, int64_t *ind);
+rc_status rc_svd_to_mat_c64(rc_context *ctx, rc_matrix u, const double *s, rc_matrix vt, rc_matrix out);
+rc_status rc_svd_to_qr_c64(rc_context *ctx, rc_matrix u, const double *s, rc_matrix vt, rc_matrix q, rc_matrix r, int64_t *ind);
+rc_status rc_svd_from_range_estimate_c64(rc_context *ctx, rc_matrix range, rc_matrix a, rc_matrix u, double *s, rc_matrix vt);
+rc_status rc_column_id_two_sided_c64(rc_context *ctx, rc_matrix c, rc_matrix c_out, rc_matrix x, int64_t *row_ind);
+rc_status rc_row_id_two_sided_c64(rc_context *ctx, rc_matrix r, rc_matrix x, rc_matrix r_out, int64_t *col_ind);
+rc_status rc_max_col_norm_c64(rc_context *ctx, rc_matrix y, double *out);
+rc_status rc_sample_range_by_rank_c64(rc_context *ctx, rc_matrix a, int64_t k, int64_t p, rc_matrix omega, uint64_t seed, rc_matrix q);
+rc_status rc_sample_range_power_iteration_c64(rc_context *ctx, rc_matrix a, int64_t k, int64_t p, int64_t it_count, rc_matrix omega, uint64_t seed, rc_matrix q);
+rc_status rc_sample_range_adaptive_c64(rc_context *ctx, rc_matrix a, double rel_tol, int64_t sample_size, rc_matrix omegas, uint64_t seed, rc_matrix q_cap, int64_t *rank, int64_t *hist_rank, double *hist_res, int64_t hist_cap, int64_t *hist_len);
+rc_status rc_column_id_rank_c64(rc_context *ctx, rc_matrix a, int64_t k, rc_matrix c, rc_matrix z, int64_t *col_ind);
+rc_status rc_random_gaussian_c32(rc_context *ctx, rc_matrix out, uint64_t seed, uint64_t offset);
+rc_status rc_matmat_c32(rc_context *ctx, rc_matrix a, rc_matrix x, rc_matrix y);
+rc_status rc_conj_matmat_c32(rc_context *ctx, rc_matrix a, rc_matrix x, rc_matrix y);
+rc_status rc_gemm_c32(rc_context *ctx, int32_t trans_a, int32_t trans_b, rc_complex32 alpha, rc_matrix a, rc_matrix b, rc_complex32 beta, rc_matrix c);
+rc_status rc_rel_diff_fro_c32(rc_context *ctx, rc_matrix first, rc_matrix second, float *out);
+rc_status rc_apply_permutation_matrix_c32(rc_context *ctx, int32_t mode, rc_matrix in, const int64_t *perm, int64_t perm_len, rc_matrix out);
+rc_status rc_apply_permutation_vector_c32(rc_context *ctx, int32_t mode, rc_matrix in, const int64_t *perm, int64_t perm_len, rc_matrix out);
+rc_status rc_pivoted_qr_c32(rc_context *ctx, rc_matrix a, rc_matrix q, rc_matrix r, int64_t *ind);
+rc_status rc_pivoted_lq_c32(rc_context *ctx, rc_matrix a, rc_matrix l, rc_matrix q, int64_t *ind);
+rc_status rc_compute_svd_c32(rc_context *ctx, rc_matrix a, rc_matrix u, float *s, rc_matrix vt);
+rc_status rc_rank_by_tolerance_c32(rc_context *ctx, rc_matrix tri, double tol, int64_t *rank);
+rc_status rc_qr_to_mat_c32(rc_context *ctx, rc_matrix q, rc_matrix r, const int64_t *ind, rc_matrix out);
+rc_status rc_lq_to_mat_c32(rc_context *ctx, rc_matrix l, rc_matrix q, const int64_t *ind, rc_matrix out);
+rc_status rc_qr_column_id_c32(rc_context *ctx, rc_matrix q, rc_matrix r, const int64_t *ind, rc_matrix c, rc_matrix z);
+rc_status rc_lq_row_id_c32(rc_context *ctx, rc_matrix l, rc_matrix q, const int64_t *ind, rc_matrix x, rc_matrix r_rows);
+rc_status rc_qr_from_range_estimate_c32(rc_context *ctx, rc_matrix range, rc_matrix a, rc_matrix q, rc_matrix r, int64_t *ind);
+rc_status rc_svd_to_mat_c32(rc_context *ctx, rc_matrix u, const float *s, rc_matrix vt, rc_matrix out);
+rc_status rc_svd_to_qr_c32(rc_context *ctx, rc_matrix u, const float *s, rc_matrix vt, rc_matrix q, rc_matrix r, int64_t *ind);
+rc_status rc_svd_from_range_estimate_c32(rc_context *ctx, rc_matrix range, rc_matrix a, rc_matrix u, float *s, rc_matrix vt);
+rc_status rc_column_id_two_sided_c32(rc_context *ctx, rc_matrix c, rc_matrix c_out, rc_matrix x, int64_t *row_ind);
+rc_status rc_row_id_two_sided_c32(rc_context *ctx, rc_matrix r, rc_matrix x, rc_matrix r_out, int64_t *col_ind);
+rc_status rc_max_col_norm_c32(rc_context *ctx, rc_matrix y, float *out);
+rc_status rc_sample_range_by_rank_c32(rc_context *ctx, rc_matrix a, int64_t k, int64_t p, rc_matrix omega, uint64_t seed, rc_matrix q);
+rc_status rc_sample_range_power_iteration_c32(rc_context *ctx, rc_matrix a, int64_t k, int64_t p, int64_t it_count, rc_matrix omega, uint64_t seed, rc_matrix q);
+rc_status rc_sample_range_adaptive_c32(rc_context *ctx, rc_matrix a, double rel_tol, int64_t sample_size, rc_matrix omegas, uint64_t seed, rc_matrix q_cap, int64_t *rank, int64_t *hist_rank, double *hist_res, int64_t hist_cap, int64_t *hist_len);
+rc_status rc_column_id_rank_c32(rc_context *ctx, rc_matrix a, int64_t k, rc_matrix c, rc_matrix z, int64_t *col_ind);
+
 #ifdef __cplusplus
 }
 #endif

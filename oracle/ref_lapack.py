@@ -39,8 +39,18 @@ from scipy.linalg import lapack as _lapack
 
 
 def _lp(name: str, dtype) -> Callable:
-    pre = {np.dtype(np.float64): "d", np.dtype(np.float32): "s"}[np.dtype(dtype)]
+    """The LAPACK routine the reference reaches for this scalar type (src/pivoted_qr.rs:187-190: s/d/c/z geqp3;
+    ?orgqr is ?ungqr for the complex types)."""
+    dt = np.dtype(dtype)
+    pre = {np.dtype(np.float64): "d", np.dtype(np.float32): "s", np.dtype(np.complex128): "z", np.dtype(np.complex64): "c"}[dt]
+    if dt.kind == "c" and name == "orgqr":
+        name = "ungqr"
     return getattr(_lapack, pre + name)
+
+
+def _h(x: np.ndarray) -> np.ndarray:
+    """Conjugate transpose (`.t().map(|item| item.conj())` in the reference); the plain transpose for real types."""
+    return x.conj().T
 
 
 class CompressionError(Exception):
@@ -137,10 +147,10 @@ def matmat(a: np.ndarray, x: np.ndarray, faithful: bool = False) -> np.ndarray:
 def conj_matmat(a: np.ndarray, x: np.ndarray, faithful: bool = False) -> np.ndarray:
     """src/types.rs:90-100 (+ :128-132, :146): out[:, j] = conj(conj(x_j) . A) = A^H x_j."""
     if not faithful:
-        return a.T @ x
+        return _h(a) @ x
     out = np.zeros((a.shape[1], x.shape[1]), dtype=a.dtype)
     for j in range(x.shape[1]):
-        out[:, j] = x[:, j].dot(a)
+        out[:, j] = np.conj(np.conj(x[:, j]).dot(a))
     return out
 
 
@@ -162,7 +172,11 @@ def rel_diff_l2(first: np.ndarray, second: np.ndarray) -> float:
 
 
 def random_gaussian(shape: Tuple[int, int], rng: np.random.Generator, dtype=np.float64) -> np.ndarray:
-    """src/random_matrix.rs:120-125: N(0,1) drawn as f64, row-major fill, cast."""
+    """src/random_matrix.rs:120-125 (real), :136-143 (complex: real and imaginary part each N(0,1), drawn in that
+    order per element): drawn as f64, row-major fill, cast."""
+    if np.dtype(dtype).kind == "c":
+        g = rng.standard_normal(tuple(shape) + (2,))
+        return (g[..., 0] + 1j * g[..., 1]).astype(dtype)
     return rng.standard_normal(shape).astype(dtype)
 
 
@@ -174,7 +188,7 @@ def random_orthogonal_matrix(shape, rng, dtype=np.float64) -> np.ndarray:
         m, n = n, m
     g = random_gaussian((m, n), rng, dtype)
     u, _, _ = compute_svd(g)
-    return u.T.copy() if swap else u
+    return _h(u).copy() if swap else u
 
 
 def random_approximate_low_rank_matrix(shape, sigma_max, sigma_min, rng, dtype=np.float64) -> np.ndarray:
@@ -184,7 +198,7 @@ def random_approximate_low_rank_matrix(shape, sigma_max, sigma_min, rng, dtype=n
     r = min(m, n)
     u = random_orthogonal_matrix((m, r), rng, dtype)
     vt = random_orthogonal_matrix((r, n), rng, dtype)
-    s = np.geomspace(sigma_min, sigma_max, r).astype(dtype)
+    s = np.geomspace(sigma_min, sigma_max, r).astype(np.empty(0, dtype).real.dtype)
     return (u @ (np.diag(s) @ vt)).astype(dtype)
 
 
@@ -221,8 +235,8 @@ def pivoted_qr(arr: np.ndarray):
 
 def pivoted_lq(arr: np.ndarray):
     """src/pivoted_qr.rs:32-41: pivoted QR of arr^H, transposed back. Returns (l, q, ind)."""
-    q, r, ind = pivoted_qr(np.ascontiguousarray(arr.T))
-    return np.ascontiguousarray(r.T), np.ascontiguousarray(q.T), ind
+    q, r, ind = pivoted_qr(np.ascontiguousarray(_h(arr)))
+    return np.ascontiguousarray(_h(r)), np.ascontiguousarray(_h(q)), ind
 
 
 # ----------------------------------------------------------------------------
@@ -317,7 +331,7 @@ class QR:
     @staticmethod
     def compute_from_range_estimate(range_: np.ndarray, op: np.ndarray, faithful: bool = False) -> "QR":
         """src/qr.rs:311-323."""
-        b = np.ascontiguousarray(conj_matmat(op, range_, faithful).T)
+        b = np.ascontiguousarray(_h(conj_matmat(op, range_, faithful)))
         qr = QR.compute_from(b)
         return QR(range_ @ qr.q, qr.r.copy(), qr.ind.copy())
 
@@ -341,8 +355,8 @@ class LQ:
     @staticmethod
     def compute_from(arr) -> "LQ":
         """src/qr.rs:354-362."""
-        q, r, ind = pivoted_qr(np.ascontiguousarray(np.asarray(arr).T))
-        return LQ(np.ascontiguousarray(r.T), np.ascontiguousarray(q.T), ind)
+        q, r, ind = pivoted_qr(np.ascontiguousarray(_h(np.asarray(arr))))
+        return LQ(np.ascontiguousarray(_h(r)), np.ascontiguousarray(_h(q)), ind)
 
     def to_mat(self) -> np.ndarray:
         """src/qr.rs:73-77."""
@@ -448,7 +462,7 @@ class SVD:
     @staticmethod
     def compute_from_range_estimate(range_: np.ndarray, op: np.ndarray, faithful: bool = False) -> "SVD":
         """src/svd.rs:171-183."""
-        b = np.ascontiguousarray(conj_matmat(op, range_, faithful).T)
+        b = np.ascontiguousarray(_h(conj_matmat(op, range_, faithful)))
         svd = SVD.compute_from(b)
         return SVD(range_ @ svd.u, svd.s.copy(), svd.vt.copy())
 
@@ -559,7 +573,7 @@ def sample_range_power_iteration(op, k, p, it_count, omega_source: OmegaSource, 
 
 def max_col_norm(mat: np.ndarray) -> float:
     """src/random_sampling.rs:184-191."""
-    mx = mat.dtype.type(0)
+    mx = np.empty(0, mat.dtype).real.dtype.type(0)
     for j in range(mat.shape[1]):
         mx = max(mx, np.linalg.norm(mat[:, j]))
     return mx
@@ -569,7 +583,7 @@ def sample_range_adaptive(op, rel_tol: float, sample_size: int, omega_source: Om
                           faithful: bool = False, max_iter: Optional[int] = None):
     """src/random_sampling.rs:223-274. Returns (q, residuals)."""
     dtype = op.dtype
-    real = dtype.type
+    real = np.empty(0, dtype).real.dtype.type
     tol_factor = real(10.0 * math.sqrt(2.0 / math.pi))
     m_rows, n = op.shape
     rel_tol_r = real(rel_tol)
@@ -583,9 +597,9 @@ def sample_range_adaptive(op, rel_tol: float, sample_size: int, omega_source: Om
     it = 0
     while max_norm / operator_norm >= rel_tol_r:
         if q.shape[1] > 0:
-            op_omega = op_omega - q @ (q.T @ op_omega)
+            op_omega = op_omega - q @ (_h(q) @ op_omega)
         qr = QR.compute_from(op_omega)
-        b = np.concatenate([b, np.ascontiguousarray(conj_matmat(op, qr.q, faithful).T)], axis=0)
+        b = np.concatenate([b, np.ascontiguousarray(_h(conj_matmat(op, qr.q, faithful)))], axis=0)
         q = np.concatenate([q, qr.q], axis=1)
         omega = omega_source((n, sample_size))
         op_omega = matmat(op, omega, faithful) - q @ (b @ omega)

@@ -120,7 +120,45 @@ def suffix(dtype) -> str:
         return "f64"
     if dtype == torch.float32:
         return "f32"
-    raise TypeError(f"unsupported scalar type {dtype}: the engine is instantiated for f32 and f64")
+    if dtype == torch.complex128:
+        return "c64"
+    if dtype == torch.complex64:
+        return "c32"
+    raise TypeError(f"unsupported scalar type {dtype}: the engine is instantiated for f32, f64, c32 and c64")
+
+
+def real_dtype(dtype):
+    """The real type of a scalar type (`<A as Scalar>::Real` in the reference): singular values, norms."""
+    import torch
+
+    return {torch.complex128: torch.float64, torch.complex64: torch.float32}.get(dtype, dtype)
+
+
+class rc_complex64(ctypes.Structure):
+    _fields_ = [("re", ctypes.c_double), ("im", ctypes.c_double)]
+
+
+class rc_complex32(ctypes.Structure):
+    _fields_ = [("re", ctypes.c_float), ("im", ctypes.c_float)]
+
+
+def scalar_arg(dtype, value: complex):
+    """A scalar of `dtype` as the C ABI takes it by value (double / float / rc_complex64 / rc_complex32)."""
+    import torch
+
+    if dtype == torch.float64:
+        return ctypes.c_double(float(value.real if isinstance(value, complex) else value))
+    if dtype == torch.float32:
+        return ctypes.c_float(float(value.real if isinstance(value, complex) else value))
+    v = complex(value)
+    return rc_complex64(v.real, v.imag) if dtype == torch.complex128 else rc_complex32(v.real, v.imag)
+
+
+def real_out(dtype):
+    """ctypes scalar receiving a real result (norms, relative differences) for `dtype`."""
+    import torch
+
+    return ctypes.c_double() if real_dtype(dtype) == torch.float64 else ctypes.c_float()
 
 
 def mat(t) -> rc_matrix:

@@ -19,7 +19,7 @@ class Rng:
 
 
 def _dtype(dtype):
-    return {"f64": torch.float64, "f32": torch.float32}.get(dtype, dtype)
+    return {"f64": torch.float64, "f32": torch.float32, "c64": torch.complex128, "c32": torch.complex64}.get(dtype, dtype)
 
 
 def random_gaussian(dimension, rng: Rng, dtype=torch.float64) -> torch.Tensor:
@@ -50,7 +50,7 @@ def random_orthogonal_matrix(dimension, rng: Rng, dtype=torch.float64) -> torch.
         m, n = n, m
     g = random_gaussian((m, n), rng, dtype)
     u = SVD.compute_from(g).u
-    return u.t().contiguous() if swap else u
+    return u.t().conj().contiguous() if swap else u  # conjugate transpose (src/random_matrix.rs:51-53)
 
 
 def random_approximate_low_rank_matrix(dimension, sigma_max: float, sigma_min: float, rng: Rng, dtype=torch.float64) -> torch.Tensor:
@@ -63,7 +63,7 @@ def random_approximate_low_rank_matrix(dimension, sigma_max: float, sigma_min: f
     u = random_orthogonal_matrix((m, r), rng, dtype)
     vt = random_orthogonal_matrix((r, n), rng, dtype)
     s = torch.logspace(torch.log10(torch.tensor(float(sigma_min))).item(), torch.log10(torch.tensor(float(sigma_max))).item(), r,
-                       dtype=torch.float64, device="cuda").to(dtype)
+                       dtype=torch.float64, device="cuda").to(_lib.real_dtype(dtype))
     from .svd import SVD
 
     return SVD(u, s, vt).to_mat()

@@ -61,7 +61,7 @@ def sample_range_power_iteration(op, k: int, p: int, it_count: int, rng_or_omega
 def max_col_norm(mat) -> float:
     """`MaxColNorm::max_col_norm` (src/random_sampling.rs:184-191)."""
     y = as_device(mat)
-    out = ctypes.c_double() if y.dtype == torch.float64 else ctypes.c_float()
+    out = _lib.real_out(y.dtype)
     _ctx().call(f"rc_max_col_norm_{_lib.suffix(y.dtype)}", _lib.mat(y), ctypes.byref(out))
     return float(out.value)
 

@@ -24,7 +24,7 @@ def compute_svd(arr):
     m, n = a.shape
     r = min(m, n)
     u, vt = empty(m, r, a), empty(r, n, a)
-    s = torch.empty(r, dtype=a.dtype, device=a.device)
+    s = torch.empty(r, dtype=_lib.real_dtype(a.dtype), device=a.device)
     _ctx().call(f"rc_compute_svd_{_lib.suffix(a.dtype)}", _lib.mat(a), _lib.mat(u), _sptr(s), _lib.mat(vt))
     return u, s, vt
 
@@ -64,7 +64,7 @@ class SVD:
     def to_mat(self) -> torch.Tensor:
         """src/svd.rs:42-54"""
         out = empty(self.nrows(), self.ncols(), self.u)
-        s = self.s.to(self.u.dtype).contiguous()
+        s = self.s.to(_lib.real_dtype(self.u.dtype)).contiguous()
         _ctx().call(f"rc_svd_to_mat_{_lib.suffix(self.u.dtype)}", _lib.mat(self.u), _sptr(s), _lib.mat(self.vt), _lib.mat(out))
         return out
 
@@ -95,7 +95,7 @@ class SVD:
         k = min(r_, n)
         q, r = empty(self.nrows(), k, self.u), empty(k, n, self.u)
         ind = torch.empty(n, dtype=torch.int64, device=self.u.device)
-        s = self.s.to(self.u.dtype).contiguous()
+        s = self.s.to(_lib.real_dtype(self.u.dtype)).contiguous()
         _ctx().call(f"rc_svd_to_qr_{_lib.suffix(self.u.dtype)}", _lib.mat(self.u), _sptr(s), _lib.mat(self.vt), _lib.mat(q), _lib.mat(r), _lib.i64p(ind))
         return QR(q, r, ind)
 
@@ -107,6 +107,6 @@ class SVD:
         m, n = a.shape
         r = min(rg.shape[1], n)
         u, vt = empty(m, r, a), empty(r, n, a)
-        s = torch.empty(r, dtype=a.dtype, device=a.device)
+        s = torch.empty(r, dtype=_lib.real_dtype(a.dtype), device=a.device)
         _ctx().call(f"rc_svd_from_range_estimate_{_lib.suffix(a.dtype)}", _lib.mat(rg), _lib.mat(a), _lib.mat(u), _sptr(s), _lib.mat(vt))
         return SVD(u, s, vt)

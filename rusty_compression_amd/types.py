@@ -89,7 +89,7 @@ def dot(a, b) -> torch.Tensor:
     b2 = b.unsqueeze(1) if vec else b
     assert a.shape[1] == b2.shape[0], "shape mismatch in dot"
     out = empty(a.shape[0], b2.shape[1], a)
-    one, zero = (ctypes.c_double(1.0), ctypes.c_double(0.0)) if a.dtype == torch.float64 else (ctypes.c_float(1.0), ctypes.c_float(0.0))
+    one, zero = _lib.scalar_arg(a.dtype, 1.0), _lib.scalar_arg(a.dtype, 0.0)
     _lib.default_context().call(f"rc_gemm_{_lib.suffix(a.dtype)}", ctypes.c_int32(0), ctypes.c_int32(0), one, _lib.mat(a), _lib.mat(b2), zero, _lib.mat(out))
     return out[:, 0] if vec else out
 
@@ -98,7 +98,7 @@ def rel_diff_fro(first, second) -> float:
     """`RelDiff::rel_diff_fro` (src/types.rs:182-188)."""
     b = as_device(second)
     a = as_device(first, b.dtype)
-    out = ctypes.c_double() if b.dtype == torch.float64 else ctypes.c_float()
+    out = _lib.real_out(b.dtype)
     _lib.default_context().call(f"rc_rel_diff_fro_{_lib.suffix(b.dtype)}", _lib.mat(a), _lib.mat(b), ctypes.byref(out))
     return float(out.value)
 

@@ -12,8 +12,10 @@ def golden(name):
 
 
 def rel(a, b):
-    a = np.asarray(a, dtype=np.float64)
-    b = np.asarray(b, dtype=np.float64)
+    a, b = np.asarray(a), np.asarray(b)
+    wide = np.complex128 if (np.iscomplexobj(a) or np.iscomplexobj(b)) else np.float64
+    a = a.astype(wide)
+    b = b.astype(wide)
     return float(np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-300))
 
 
@@ -53,7 +55,7 @@ def stable_prefix(r, dtype):
     dropped to the rounding level of the working precision the remaining columns
     are numerical noise and their order legitimately depends on summation order
     (SURVEY.md F8).  Pivot indices are compared bit-exactly on this prefix only."""
-    d = np.abs(np.diag(np.asarray(r, dtype=np.float64)))
+    d = np.abs(np.diag(np.asarray(r))).astype(np.float64)
     floor = {np.dtype(np.float64): 1e-12, np.dtype(np.float32): 2e-5}[np.dtype(dtype)] * d[0]
     below = np.nonzero(d < floor)[0]
     return int(below[0]) if below.size else int(d.size)
@@ -78,6 +80,6 @@ def agreed_pivot_prefix(ind, r, ind_ref, r_ref, dtype):
         return ns
     j = int(diff[0])
     tie = {np.dtype(np.float64): 1e-6, np.dtype(np.float32): 5e-3}[np.dtype(dtype)]
-    a, b = abs(float(r[j, j])), abs(float(r_ref[j, j]))
+    a, b = float(abs(r[j, j])), float(abs(r_ref[j, j]))
     assert abs(a - b) <= tie * max(a, b), f"pivot {j} differs and is not a near tie: |r_jj| {a} vs {b}"
     return j
