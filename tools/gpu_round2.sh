@@ -15,3 +15,5 @@ echo "== bench driver-style (--steps 20 --warmup 5)" | tee -a gpurun_out/progres
 timeout -k 10 400 python bench.py --steps 20 --warmup 5 > gpurun_out/bench_driver.json 2> gpurun_out/bench_driver.err || { echo "bench failed"; tail -5 gpurun_out/bench_driver.err; exit 1; }
 python -c "
 import json; d=json.load(open('gpurun_out/bench_driver.json')); print('driver-style:', d['value'], 'c/s', d['ms_per_step'], 'ms/step', 'frac', d['frac_of_f64_mfma_peak_whole_pipeline'], 'roofline', d['roofline']['achieved'], d['roofline']['frac'], 'cpu', d['cpu_baseline']['value'], d['cpu_baseline_gemm_form']['value'], 'h2d', d['value_including_h2d'])"
+echo "== smoke" | tee -a gpurun_out/progress.log
+timeout -k 10 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -3
