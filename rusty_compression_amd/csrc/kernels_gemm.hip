@@ -21,6 +21,7 @@
 //    linear id is remapped to give each XCD a contiguous run of row tiles that
 //    share the B panel in that XCD's L2.
 #include "rc_common.hpp"
+#include "rc_gemm.hpp"
 
 #include <cstdlib>
 
@@ -51,21 +52,6 @@ template <> struct Acc<float> {
 constexpr int pitch16(int n) { return n + ((16 - n % 32) + 32) % 32; }
 // smallest pitch >= n with pitch % 8 == 4 (same for the 4x4x4 f64 MFMA fragments)
 constexpr int pitch4(int n) { return n + ((4 - n % 8) + 8) % 8; }
-
-template <typename T>
-struct GemmArgs {
-    const T *a, *b;
-    T *c;
-    int64_t M, N, K;
-    int64_t sam, sak;  // A(m, k)
-    int64_t sbk, sbn;  // B(k, n)
-    int64_t scm, scn;  // C(m, n)
-    T alpha, beta;
-    int64_t kchunk;    // K range per split
-    int splits;
-    T *partial;        // [splits][M][N] when splits > 1
-    int tiles_m, tiles_n;
-};
 
 // One operand tile: R rows (the operand's non-reduction index) x BK, staged by NT threads.
 //   LAY == 0: the reduction index k is contiguous in memory (stride_k == 1 when VEC == 2)
@@ -636,7 +622,8 @@ static void launch_f64q(rc_context *c, GemmArgs<double> g) {
         snprintf(nm, sizeof(nm), "k_gemm_f64q<%d,%d,%d,%d,%d,%d,%d,%d,%d,%d>", ALAY, BLAY, BM, BN, BK, WM, WN, VEC, ORIENT, GLDS);
         c->last_gemm_kernel = nm;
     }
-    {
+    // the software-pipelined main loop (kernels_gemm_pipe.hip) where it has an instantiation for this tile shape
+    if (!gemm_f64p_launch(c, g, ALAY, BLAY, BM, BN, BK, WM, WN, ORIENT, VEC == 2)) {
         ProfScope ps(c, "kernel:k_gemm_mfma<f64> M=%lld N=%lld K=%lld", (long long)g.M, (long long)g.N, (long long)g.K);
         hipLaunchKernelGGL(kern, dim3((unsigned)tiles, (unsigned)splits), dim3(NT), lds, c->stream, g);
     }

@@ -1,0 +1,511 @@
+// Software-pipelined f64 MFMA GEMM main loop for gfx950 (the two big products of a compression: the sketch Y = A Omega and
+// the projection B = Q^H A; they replace the reference's per-column gemv loops, /root/reference/src/types.rs:60-70, :90-100).
+//
+// Same tiles, LDS images and v_mfma_f64_4x4x4_4b micro-tiling as k_gemm_f64q (kernels_gemm.hip), different schedule.  In
+// k_gemm_f64q every K sub-step (4 of them per 16-deep K tile) first issues its TM + TN fragment reads and waits for ALL of
+// them before the first MFMA: with two waves per SIMD running in step, the matrix pipe idles for one LDS round trip per
+// sub-step, and once more per tile around the LDS stores and the barrier (PMC: matrix pipe busy 73 %).  Here
+//   * the A fragments ROTATE: the read of sub-step s + 1's fragment i is issued right behind the TN MFMAs that consumed
+//     sub-step s's fragment i, into the same register; the B fragments are double buffered (TN more registers).  Every
+//     fragment read has a whole sub-step of MFMAs (> 1000 cycles) to arrive, the waits are counted (s_waitcnt lgkmcnt(n));
+//   * the ONE barrier per K tile sits between the last two sub-steps: the next tile's LDS stores are issued at the start
+//     of sub-step NKS - 2, the barrier follows that sub-step's MFMAs, and sub-step NKS - 1 already prefetches the first
+//     fragments of the next tile from the other buffer.  No fragment read, LDS store or global load is waited for with an
+//     empty matrix pipe;
+//   * the global loads are branch free (rows beyond the matrix are clamped to its last row / row pair: they only feed output
+//     rows that are never stored; the K range must be whole tiles, which the host checks), so a K tile is ONE basic block
+//     whose order is pinned with sched_group_barrier.
+#include "rc_gemm.hpp"
+
+namespace rc {
+
+typedef double pdouble2_t __attribute__((ext_vector_type(2)));
+typedef unsigned int pint4_t __attribute__((ext_vector_type(4)));
+
+constexpr int pp_pitch16(int n) { return n + ((16 - n % 32) + 32) % 32; }
+
+// One operand tile: R rows x BK, staged by NT threads with 16-byte vectors.
+//   LAY == 0: the reduction index is contiguous in memory ; LAY == 1: the row index is contiguous in memory.
+// LDS image as in TileStager (kernels_gemm.hip): LAY == 0 -> [R][BK + 2], LAY == 1 -> [BK][pitch16(R)].
+// Slots beyond the tile's NVEC vectors duplicate the vectors of other threads (same address, same value) instead of being
+// predicated off, so the staging code has no branches.
+template <int LAY, int R, int BK, int NT>
+struct PipeStage {
+    static constexpr int P = LAY == 0 ? BK + 2 : pp_pitch16(R);
+    static constexpr int ELEMS = LAY == 0 ? R * P : BK * P;
+    static constexpr int NVEC = R * BK / 2;
+    static constexpr int PER_T = (NVEC + NT - 1) / NT;
+    static_assert(PER_T * NT <= 2 * NVEC && R % 2 == 0 && BK % 2 == 0, "staging shape");
+
+    uint32_t goff[PER_T];  // byte offset of the vector from the tile's first element (buffer load: lane offset + scalar tile offset)
+    pint4_t val[PER_T];
+
+    static __device__ inline void coords(int idx, int &r, int &k) {
+        if (idx >= NVEC) idx -= NVEC;
+        if (LAY == 0) { k = (idx % (BK / 2)) * 2; r = idx / (BK / 2); }
+        else { r = (idx % (R / 2)) * 2; k = idx / (R / 2); }
+    }
+    // rows_left = rows of the matrix from the tile's first row on (>= 1)
+    __device__ inline void init(int64_t rows_left, int64_t sr, int64_t sk, int tid) {
+        const int rclamp = (int)min((int64_t)R, rows_left) - 1;
+#pragma unroll
+        for (int e = 0; e < PER_T; ++e) {
+            int r, k;
+            coords(tid + e * NT, r, k);
+            if (LAY == 0) r = min(r, rclamp);
+            else r = min(r, rclamp & ~1);
+            goff[e] = (uint32_t)((r * sr + k * sk) * 8);
+        }
+    }
+    // tile_off: byte offset of the K tile from the buffer's base (uniform)
+    __device__ inline void load(__amdgpu_buffer_rsrc_t rsrc, uint32_t tile_off) {
+#pragma unroll
+        for (int e = 0; e < PER_T; ++e) val[e] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, goff[e], tile_off, 0);
+    }
+    __device__ inline void store(double *lds, int tid) const {
+#pragma unroll
+        for (int e = 0; e < PER_T; ++e) {
+            int r, k;
+            coords(tid + e * NT, r, k);
+            *reinterpret_cast<pint4_t *>(lds + (LAY == 0 ? r * P + k : k * P + r)) = val[e];
+        }
+    }
+};
+
+// ALAY: 0 = A is K-contiguous, 1 = A is M-contiguous ; BLAY: 0 = B is N-contiguous, 1 = B is K-contiguous
+// ORIENT 0: A micro tile 4 rows, B micro tile 16 columns ; ORIENT 1: 16 rows / 4 columns (see k_gemm_f64q)
+template <int ALAY, int BLAY, int BM, int BN, int BK, int WM, int WN, int ORIENT, int DBG = 0>
+__global__ __launch_bounds__(WM *WN * 64) void k_gemm_f64p(GemmArgs<double> g) {
+    constexpr int NT = WM * WN * 64;
+    constexpr int WR = BM / WM, WC = BN / WN;
+    constexpr int AM = ORIENT == 0 ? 4 : 16, BNW = ORIENT == 0 ? 16 : 4;
+    constexpr int TM = WR / AM, TN = WC / BNW;
+    constexpr int LA = ALAY, LB = BLAY == 1 ? 0 : 1;
+    constexpr int NKS = BK / 4;
+    static_assert(WR % AM == 0 && WC % BNW == 0 && NKS >= 2, "tile shape");
+    typedef PipeStage<LA, BM, BK, NT> SA;
+    typedef PipeStage<LB, BN, BK, NT> SB;
+    constexpr int PA = SA::P, PB = SB::P, A_ELEMS = SA::ELEMS, STAGE = SA::ELEMS + SB::ELEMS;
+
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    double *smem = reinterpret_cast<double *>(smem_raw);
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int lk = lane >> 4;
+    const int la = ORIENT == 0 ? (lane & 3) : (lane & 15);
+    const int lbn = ORIENT == 0 ? (lane & 15) : (lane & 3);
+
+    const int ntiles = g.tiles_m * g.tiles_n;
+    int bid = blockIdx.x;
+    {
+        const int q = ntiles / 8, r = ntiles % 8, xcd = bid % 8, idx = bid / 8;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    const int tile_n = bid % g.tiles_n, tile_m = bid / g.tiles_n;
+    const int64_t m0 = (int64_t)tile_m * BM, n0 = (int64_t)tile_n * BN;
+    const int split = blockIdx.y;
+    const int64_t kbeg = (int64_t)split * g.kchunk;
+    const int64_t kend = min(g.K, kbeg + g.kchunk);
+    const int nk = (int)((kend - kbeg) / BK);  // whole tiles (host-checked), >= 1
+
+    double acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = 0.0;
+
+    SA sa;
+    SB sb;
+    sa.init(g.M - m0, g.sam, g.sak, tid);
+    sb.init(g.N - n0, g.sbn, g.sbk, tid);
+    // buffer resources based at this workgroup's first tile: lane offsets and tile offsets are 32-bit (host-checked spans)
+    const __amdgpu_buffer_rsrc_t a_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<double *>(g.a + m0 * g.sam + kbeg * g.sak), 0, 0x7fffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t b_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<double *>(g.b + n0 * g.sbn + kbeg * g.sbk), 0, 0x7fffffff, 0x00020000);
+    const uint32_t a_step = (uint32_t)(BK * g.sak * 8), b_step = (uint32_t)(BK * g.sbk * 8);
+
+    // fragment addresses of this lane inside a stage (doubles)
+    const int a_lane = LA == 1 ? lk * PA + wm * WR + la : (wm * WR + la) * PA + lk;
+    const int b_lane = LB == 0 ? (wn * WC + lbn) * PB + lk : lk * PB + wn * WC + lbn;
+    auto a_frag = [&](const double *st, int ks, int i) -> double {
+        return st[a_lane + (LA == 1 ? ks * 4 * PA + i * AM : i * AM * PA + ks * 4)];
+    };
+    auto b_frag = [&](const double *st, int ks, int j) -> double {
+        return st[A_ELEMS + b_lane + (LB == 0 ? j * BNW * PB + ks * 4 : ks * 4 * PB + j * BNW)];
+    };
+
+    // ---- prologue: tile 0 into buffer 0, tile 1 into the staging registers, fragments of (tile 0, sub-step 0) ------------
+    sa.load(a_rsrc, 0);
+    sb.load(b_rsrc, 0);
+    sa.store(smem, tid);
+    sb.store(smem + A_ELEMS, tid);
+    {
+        const int t1 = min(1, nk - 1);
+        sa.load(a_rsrc, t1 * a_step);
+        sb.load(b_rsrc, t1 * b_step);
+    }
+    __syncthreads();
+    double af[TM], bf[2][TN];
+#pragma unroll
+    for (int j = 0; j < TN; ++j) bf[0][j] = b_frag(smem, 0, j);
+#pragma unroll
+    for (int i = 0; i < TM; ++i) af[i] = a_frag(smem, 0, i);
+
+    for (int it = 0; it < nk; ++it) {
+        const double *cur = smem + (it & 1) * STAGE;
+        double *nxt = smem + ((it & 1) ^ 1) * STAGE;
+#pragma unroll
+        for (int ks = 0; ks < NKS; ++ks) {
+            constexpr int dummy = 0;
+            (void)dummy;
+            if (ks == NKS - 2 && !(DBG & 1)) {
+                // tile it + 1 (in the staging registers since the previous barrier) -> the other buffer; every wave finished
+                // reading that buffer before the previous barrier
+                sa.store(nxt, tid);
+                sb.store(nxt + A_ELEMS, tid);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            // the fragments of the next sub-step: same buffer, or sub-step 0 of the other buffer behind the barrier
+            const double *fs = ks + 1 < NKS ? cur : nxt;
+            const int nks = ks + 1 < NKS ? ks + 1 : 0;
+            const int pb = ks & 1, qb = pb ^ 1;
+#pragma unroll
+            for (int j = 0; j < TN; ++j) bf[qb][j] = b_frag(fs, nks, j);
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+#pragma unroll
+                for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f64_4x4x4f64(af[i], bf[pb][j], acc[i][j], 0, 0, 0);
+                af[i] = a_frag(fs, nks, i);
+            }
+            // pin the order above: TN reads, then TM x (TN MFMAs, 1 read)
+            __builtin_amdgcn_sched_group_barrier(0x100, TN, 0);
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                __builtin_amdgcn_sched_group_barrier(0x008, TN, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            if (ks == NKS - 2) {
+                // the LDS stores above have landed and this wave's reads of `cur` are complete
+                if (!(DBG & 2)) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+                const int t2 = min(it + 2, nk - 1);
+                if (!(DBG & 1)) {
+                    sa.load(a_rsrc, t2 * a_step);
+                    sb.load(b_rsrc, t2 * b_step);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    }
+
+    // ---- epilogue (k_gemm_f64q's): D lane l = 16*i + 4*b + j -----------------------------------------------------------
+    const int er = ORIENT == 0 ? (lane >> 4) : (((lane >> 2) & 3) * 4 + (lane >> 4));
+    const int ec = ORIENT == 0 ? (lane & 15) : (lane & 3);
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int64_t gm = m0 + wm * WR + i * AM + er;
+            const int64_t gn = n0 + wn * WC + j * BNW + ec;
+            if (gm < g.M && gn < g.N) {
+                const double v = acc[i][j];
+                if (g.splits > 1) {
+                    g.partial[((int64_t)split * g.M + gm) * g.N + gn] = v;
+                } else {
+                    double *cp = g.c + gm * g.scm + gn * g.scn;
+                    *cp = g.beta == 0.0 ? g.alpha * v : g.alpha * v + g.beta * (*cp);
+                }
+            }
+        }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Direct-to-LDS variant: the operand tiles go global -> LDS with buffer_load_dwordx4 ... lds (no staging registers, no LDS
+// store instructions), one 1 KiB piece per wave instruction.  The copies of tile it + 2 are issued right behind the
+// barrier of tile it and are waited for (vmcnt(0)) only in front of the barrier of tile it + 1: a whole tile in flight.
+// ---------------------------------------------------------------------------------------------------------------------
+typedef __attribute__((address_space(3))) void *lds_ptr_t;
+
+// Operand stored with its ROW index contiguous (unit row stride, `sk` between reduction indices): LDS image [BK][P],
+// one piece = 128 consecutive rows of one reduction index.  R <= 128 -> P = 144; R <= 256 -> P = 272 (the second piece
+// of a row is always copied whole -- 1 KiB -- so the pitch covers 256 rows; lanes beyond the matrix re-read its last pair).
+template <int R, int BK, int NT>
+struct DirectRows {
+    static constexpr int PIECES_ROW = (R + 127) / 128;
+    static constexpr int P = R <= 128 ? pp_pitch16(128) : pp_pitch16(256);
+    static constexpr int ELEMS = BK * P;
+    static constexpr int NW = NT / 64;
+    static constexpr int PER_WAVE = BK * PIECES_ROW / NW;
+    static_assert(BK * PIECES_ROW % NW == 0 && PER_WAVE >= 1 && R <= 256, "direct-to-LDS tile (row-contiguous operand): shape");
+    uint32_t voff[PIECES_ROW];
+    uint32_t sk8;
+    __device__ inline void init(int64_t rows_left, int64_t sk, int lane) {
+        const int rclamp = ((int)min((int64_t)R, rows_left) - 1) & ~1;
+#pragma unroll
+        for (int h = 0; h < PIECES_ROW; ++h) voff[h] = (uint32_t)(min(h * 128 + 2 * lane, rclamp) * 8);
+        sk8 = (uint32_t)(sk * 8);
+    }
+    __device__ inline void copy(__amdgpu_buffer_rsrc_t rsrc, uint32_t tile_off, double *stage, int wave_u) const {
+        static_assert(PER_WAVE % PIECES_ROW == 0, "a wave copies whole rows");
+#pragma unroll
+        for (int i = 0; i < PER_WAVE; ++i) {
+            const int kk = wave_u * (PER_WAVE / PIECES_ROW) + i / PIECES_ROW;  // uniform
+            constexpr int dummy = 0;
+            (void)dummy;
+            const int h = i % PIECES_ROW;                                       // compile time
+            const uint32_t soff = __builtin_amdgcn_readfirstlane(tile_off + kk * sk8);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_ptr_t)(stage + kk * P + h * 128), 16, voff[h], soff, 0, 0);
+        }
+    }
+    // fragment address (doubles) of row r, reduction index k
+    static __device__ inline int at(int r, int k) { return k * P + r; }
+};
+
+// Operand stored with its REDUCTION index contiguous (16 doubles = 128 bytes of a row per K tile, `sr` between rows): one
+// piece = 8 rows; LDS image [R][16], unpadded, the eight 16-byte chunks of row n stored at position chunk ^ ((n >> 1) & 7)
+// (applied to the per-lane SOURCE address), which keeps the 4 x 16 fragment reads at two passes.  Needs whole tiles of rows.
+template <int R, int BK, int NT>
+struct DirectK {
+    static constexpr int ELEMS = R * BK;
+    static constexpr int NW = NT / 64;
+    static constexpr int PER_WAVE = R / 8 / NW;
+    static_assert(BK == 16 && R % (8 * NW) == 0 && PER_WAVE % 2 == 0, "direct-to-LDS tile (K-contiguous operand): shape");
+    uint32_t voff[2];  // by the parity of the piece
+    uint32_t sr64;     // 8 rows in bytes
+    __device__ inline void init(int64_t sr, int lane) {
+#pragma unroll
+        for (int par = 0; par < 2; ++par) {
+            const int chunk = (lane & 7) ^ ((par * 4 + (lane >> 4)) & 7);
+            voff[par] = (uint32_t)((lane >> 3) * sr * 8 + chunk * 16);
+        }
+        sr64 = (uint32_t)(sr * 64);
+    }
+    __device__ inline void copy(__amdgpu_buffer_rsrc_t rsrc, uint32_t tile_off, double *stage, int wave_u) const {
+#pragma unroll
+        for (int i = 0; i < PER_WAVE; ++i) {
+            const int piece = wave_u * PER_WAVE + i;  // uniform; its parity is i's (PER_WAVE is even)
+            const uint32_t soff = __builtin_amdgcn_readfirstlane(tile_off + piece * sr64);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_ptr_t)(stage + piece * 8 * BK), 16, voff[i & 1], soff, 0, 0);
+        }
+    }
+};
+
+// ALAY must be 1 (A row-contiguous).  BLAY 0: B row(N)-contiguous (DirectRows) ; BLAY 1: B K-contiguous (DirectK, ORIENT 0 only)
+template <int BLAY, int BM, int BN, int BK, int WM, int WN, int ORIENT>
+__global__ __launch_bounds__(WM *WN * 64) void k_gemm_f64d(GemmArgs<double> g) {
+    constexpr int NT = WM * WN * 64;
+    constexpr int WR = BM / WM, WC = BN / WN;
+    constexpr int AM = ORIENT == 0 ? 4 : 16, BNW = ORIENT == 0 ? 16 : 4;
+    constexpr int TM = WR / AM, TN = WC / BNW;
+    constexpr int NKS = BK / 4;
+    static_assert(WR % AM == 0 && WC % BNW == 0 && NKS >= 2 && (BLAY == 0 || ORIENT == 0), "tile shape");
+    typedef DirectRows<BM, BK, NT> SA;
+    typedef DirectRows<BN, BK, NT> SBR;
+    typedef DirectK<BN, BK, NT> SBK;
+    constexpr int PA = SA::P, PBR = SBR::P;
+    constexpr int A_ELEMS = SA::ELEMS, STAGE = SA::ELEMS + (BLAY == 0 ? SBR::ELEMS : SBK::ELEMS);
+
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    double *smem = reinterpret_cast<double *>(smem_raw);
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    const int wm = wave / WN, wn = wave % WN;
+    const int lk = lane >> 4;
+    const int la = ORIENT == 0 ? (lane & 3) : (lane & 15);
+    const int lbn = ORIENT == 0 ? (lane & 15) : (lane & 3);
+
+    const int ntiles = g.tiles_m * g.tiles_n;
+    int bid = blockIdx.x;
+    {
+        const int q = ntiles / 8, r = ntiles % 8, xcd = bid % 8, idx = bid / 8;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    const int tile_n = bid % g.tiles_n, tile_m = bid / g.tiles_n;
+    const int64_t m0 = (int64_t)tile_m * BM, n0 = (int64_t)tile_n * BN;
+    const int split = blockIdx.y;
+    const int64_t kbeg = (int64_t)split * g.kchunk;
+    const int64_t kend = min(g.K, kbeg + g.kchunk);
+    const int nk = (int)((kend - kbeg) / BK);  // whole tiles (host-checked), >= 1
+
+    double acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = 0.0;
+
+    SA sa;
+    SBR sbr;
+    SBK sbk;
+    sa.init(g.M - m0, g.sak, lane);
+    if (BLAY == 0) sbr.init(g.N - n0, g.sbk, lane);
+    else sbk.init(g.sbn, lane);
+    const __amdgpu_buffer_rsrc_t a_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<double *>(g.a + m0 * g.sam + kbeg * g.sak), 0, 0x7fffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t b_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<double *>(g.b + n0 * g.sbn + kbeg * g.sbk), 0, 0x7fffffff, 0x00020000);
+    const uint32_t a_step = (uint32_t)(BK * g.sak * 8), b_step = (uint32_t)(BK * g.sbk * 8);
+    auto copy_tile = [&](int t, double *stage) {
+        sa.copy(a_rsrc, t * a_step, stage, wave_u);
+        if (BLAY == 0) sbr.copy(b_rsrc, t * b_step, stage + A_ELEMS, wave_u);
+        else sbk.copy(b_rsrc, t * b_step, stage + A_ELEMS, wave_u);
+    };
+
+    // fragment addresses of this lane inside a stage (doubles)
+    const int a_lane = lk * PA + wm * WR + la;
+    auto a_frag = [&](const double *st, int ks, int i) -> double { return st[a_lane + ks * 4 * PA + i * AM]; };
+    // B row-contiguous: [BK][PBR] ; B K-contiguous: swizzled [BN][16], (nn >> 1) & 7 == (lbn >> 1) & 7 (ORIENT 0: nn = 16 * x + lbn)
+    const int b_lane = BLAY == 0 ? lk * PBR + wn * WC + lbn : (wn * WC + lbn) * BK + (lk & 1);
+    const int b_swz = (((lk >> 1) ^ (lbn >> 1)) & 7) * 2;
+    auto b_frag = [&](const double *st, int ks, int j) -> double {
+        if (BLAY == 0) return st[A_ELEMS + b_lane + ks * 4 * PBR + j * BNW];
+        return st[A_ELEMS + b_lane + j * BNW * BK + (b_swz ^ (ks * 4))];
+    };
+
+    // ---- prologue --------------------------------------------------------------------------------------------------------
+    copy_tile(0, smem);
+    copy_tile(min(1, nk - 1), smem + STAGE);
+    asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+    double fa[2][TM], fb[2][TN];
+#pragma unroll
+    for (int j = 0; j < TN; ++j) fb[0][j] = b_frag(smem, 0, j);
+#pragma unroll
+    for (int i = 0; i < TM; ++i) fa[0][i] = a_frag(smem, 0, i);
+
+    for (int it = 0; it < nk; ++it) {
+        double *cur = smem + (it & 1) * STAGE;
+        const double *nxt = smem + ((it & 1) ^ 1) * STAGE;
+#pragma unroll
+        for (int ks = 0; ks < NKS; ++ks) {
+            // the fragments of the next sub-step: same buffer, or sub-step 0 of the other buffer (behind the barrier)
+            const double *fs = ks + 1 < NKS ? cur : nxt;
+            const int nks = ks + 1 < NKS ? ks + 1 : 0;
+            const int pb = ks & 1, qb = pb ^ 1;
+#pragma unroll
+            for (int j = 0; j < TN; ++j) fb[qb][j] = b_frag(fs, nks, j);
+#pragma unroll
+            for (int i = 0; i < TM; ++i) fa[qb][i] = a_frag(fs, nks, i);
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f64_4x4x4f64(fa[pb][i], fb[pb][j], acc[i][j], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (ks == NKS - 2) {
+                // tile it + 1 has landed in `nxt` (copies issued behind the previous barrier); this wave's reads of `cur` are
+                // complete, so behind the barrier `cur` is free for tile it + 2
+                asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+                copy_tile(min(it + 2, nk - 1), cur);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    }
+    // the (redundant) copies of the last iterations must not outlive the workgroup's LDS allocation
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+
+    const int er = ORIENT == 0 ? (lane >> 4) : (((lane >> 2) & 3) * 4 + (lane >> 4));
+    const int ec = ORIENT == 0 ? (lane & 15) : (lane & 3);
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int64_t gm = m0 + wm * WR + i * AM + er;
+            const int64_t gn = n0 + wn * WC + j * BNW + ec;
+            if (gm < g.M && gn < g.N) {
+                const double v = acc[i][j];
+                if (g.splits > 1) {
+                    g.partial[((int64_t)split * g.M + gm) * g.N + gn] = v;
+                } else {
+                    double *cp = g.c + gm * g.scm + gn * g.scn;
+                    *cp = g.beta == 0.0 ? g.alpha * v : g.alpha * v + g.beta * (*cp);
+                }
+            }
+        }
+}
+
+template <int BLAY, int BM, int BN, int BK, int WM, int WN, int ORIENT>
+static bool launch_d(rc_context *c, const GemmArgs<double> &g) {
+    constexpr int NT = WM * WN * 64;
+    constexpr size_t lds = 2 * (size_t)(DirectRows<BM, BK, NT>::ELEMS + (BLAY == 0 ? DirectRows<BN, BK, NT>::ELEMS : DirectK<BN, BK, NT>::ELEMS)) * sizeof(double);
+    static_assert(lds <= 160 * 1024, "tile does not fit LDS");
+    // unit row stride of A; B: unit column stride (BLAY 0) or unit K stride with whole tiles of columns (BLAY 1)
+    if (g.sam != 1) return false;
+    if (BLAY == 0 ? g.sbn != 1 : (g.sbk != 1 || g.N % BN != 0)) return false;
+    // 32-bit byte offsets from a workgroup's first element over its whole K chunk
+    const int64_t a_span = ((int64_t)256 * g.sam + g.kchunk * g.sak + 2) * 8;
+    const int64_t b_span = ((int64_t)BN * g.sbn + g.kchunk * g.sbk + 2) * 8;
+    if (a_span >= (1ll << 31) || b_span >= (1ll << 31) || g.sak < 0 || g.sbn < 0 || g.sbk < 0) return false;
+    auto kern = k_gemm_f64d<BLAY, BM, BN, BK, WM, WN, ORIENT>;
+    static bool attr_set[64] = {};
+    if (lds > 48 * 1024 && !attr_set[c->device & 63]) {
+        RC_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_set[c->device & 63] = true;
+    }
+    char nm[128];
+    snprintf(nm, sizeof(nm), "k_gemm_f64d<%d,%d,%d,%d,%d,%d,%d>", BLAY, BM, BN, BK, WM, WN, ORIENT);
+    c->last_gemm_kernel = nm;
+    ProfScope ps(c, "kernel:k_gemm_mfma<f64> M=%lld N=%lld K=%lld", (long long)g.M, (long long)g.N, (long long)g.K);
+    hipLaunchKernelGGL(kern, dim3((unsigned)(g.tiles_m * g.tiles_n), (unsigned)g.splits), dim3(NT), lds, c->stream, g);
+    return true;
+}
+
+template <int ALAY, int BLAY, int BM, int BN, int BK, int WM, int WN, int ORIENT, int DBG = 0>
+static bool launch_p(rc_context *c, const GemmArgs<double> &g) {
+    constexpr int NT = WM * WN * 64;
+    typedef PipeStage<ALAY, BM, BK, NT> SA;
+    typedef PipeStage<BLAY == 1 ? 0 : 1, BN, BK, NT> SB;
+    constexpr size_t lds = 2 * (size_t)(SA::ELEMS + SB::ELEMS) * sizeof(double);
+    static_assert(lds <= 160 * 1024, "tile does not fit LDS");
+    // 32-bit byte offsets from a workgroup's first element over its whole K chunk
+    const int64_t a_span = ((int64_t)BM * g.sam + g.kchunk * g.sak + 2) * 8;
+    const int64_t b_span = ((int64_t)BN * g.sbn + g.kchunk * g.sbk + 2) * 8;
+    if (a_span >= (1ll << 31) || b_span >= (1ll << 31) || g.sam < 0 || g.sak < 0 || g.sbn < 0 || g.sbk < 0) return false;
+    auto kern = k_gemm_f64p<ALAY, BLAY, BM, BN, BK, WM, WN, ORIENT, DBG>;
+    static bool attr_set[64] = {};
+    if (lds > 48 * 1024 && !attr_set[c->device & 63]) {
+        RC_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_set[c->device & 63] = true;
+    }
+    char nm[128];
+    snprintf(nm, sizeof(nm), "k_gemm_f64p<%d,%d,%d,%d,%d,%d,%d,%d>", ALAY, BLAY, BM, BN, BK, WM, WN, ORIENT);
+    c->last_gemm_kernel = nm;
+    ProfScope ps(c, "kernel:k_gemm_mfma<f64> M=%lld N=%lld K=%lld", (long long)g.M, (long long)g.N, (long long)g.K);
+    hipLaunchKernelGGL(kern, dim3((unsigned)(g.tiles_m * g.tiles_n), (unsigned)g.splits), dim3(NT), lds, c->stream, g);
+    return true;
+}
+
+bool gemm_f64p_launch(rc_context *c, const GemmArgs<double> &g, int alay, int blay, int bm, int bn, int bk, int wm, int wn, int orient, bool vec2) {
+    static const int use = [] { const char *e = getenv("RC_GEMM_PIPE"); return e ? atoi(e) : 1; }();
+    if (!use || !vec2 || bk != 16) return false;
+    // whole K tiles in every split, at least one
+    if (g.K % bk != 0 || g.kchunk % bk != 0 || g.K < bk) return false;
+#define RC_PIPE_CASE(AL, BL, BM_, BN_, WM_, WN_, OR_)                                                              \
+    if (alay == AL && blay == BL && bm == BM_ && bn == BN_ && wm == WM_ && wn == WN_ && orient == OR_)             \
+        return launch_p<AL, BL, BM_, BN_, 16, WM_, WN_, OR_>(c, g);
+#ifdef RC_GEMM_PIPE_DEBUG
+    {
+        static const int dbg = [] { const char *e = getenv("RC_GEMM_PIPE_DBG"); return e ? atoi(e) : 0; }();
+        if (alay == 1 && blay == 0 && bm == 128 && bn == 256 && wm == 1 && wn == 8 && orient == 1) {
+            if (dbg == 1) return launch_p<1, 0, 128, 256, 16, 1, 8, 1, 1>(c, g);
+            if (dbg == 2) return launch_p<1, 0, 128, 256, 16, 1, 8, 1, 2>(c, g);
+            if (dbg == 3) return launch_p<1, 0, 128, 256, 16, 1, 8, 1, 3>(c, g);
+        }
+    }
+#endif
+    // RC_GEMM_PIPE_DIRECT: 1 (default) = direct-to-LDS copies where they measured faster (the sketch: 377 -> 358 us; its
+    // register-staged instance spills), 2 = also for the projection (325 us against 321 us register-staged), 0 = never
+    static const int direct = [] { const char *e = getenv("RC_GEMM_PIPE_DIRECT"); return e ? atoi(e) : 1; }();
+    if (direct && alay == 1 && bk == 16) {
+        if (blay == 1 && bm == 136 && bn == 256 && wm == 2 && wn == 4 && orient == 0 && launch_d<1, 136, 256, 16, 2, 4, 0>(c, g)) return true;
+        if (direct >= 2 && blay == 0 && bm == 128 && bn == 256 && wm == 1 && wn == 8 && orient == 1 && launch_d<0, 128, 256, 16, 1, 8, 1>(c, g)) return true;
+    }
+    RC_PIPE_CASE(1, 1, 136, 256, 2, 4, 0)  // the sketch (transposed problem): 68 x 64 wave tiles
+    RC_PIPE_CASE(1, 0, 128, 256, 1, 8, 1)  // the projection: 128 x 32 wave tiles
+#undef RC_PIPE_CASE
+    return false;
+}
+
+}  // namespace rc
+
+namespace rc {
+// (explicit: clang did not emit the host stub of the second instantiation from its use inside the `&&` chain above)
+template __global__ void k_gemm_f64d<1, 136, 256, 16, 2, 4, 0>(GemmArgs<double>);
+template __global__ void k_gemm_f64d<0, 128, 256, 16, 1, 8, 1>(GemmArgs<double>);
+}
