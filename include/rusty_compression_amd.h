@@ -141,8 +141,14 @@ rc_status rc_graph_destroy(rc_context *ctx, void *graph_exec);
  * compressions in flight the other streams fill the chip, and un-split products are cheaper (no partial slabs, no
  * reduction kernel): with a hint >= 8 a product with >= 32 output tiles is not split.  Results are deterministic for a
  * given hint; different hints differ by summation order only. */
+/* RC_OPT_COOP_PANEL (default 1): the steps of a blocked-QRCP panel run as ONE cooperative launch with the candidate columns
+ * resident in registers (one grid barrier per step instead of two kernel boundaries; the candidates are read and written once
+ * per panel) whenever the active rows fit (m - j0 <= 4096 in f32, 3072 in f64) and the candidates fit its 512 waves; a launch
+ * that cannot run (too many tied candidates, workgroups not co-resident in time) leaves the panel untouched and the step
+ * kernels take it.  Same pivot rule; the candidates' norms are down-dated with ?laqp2's formula (their columns are kept up to
+ * date, so a norm that loses its accuracy is recomputed on the spot instead of ending the panel).  0 = step kernels only. */
 enum { RC_OPT_TALL_SKINNY_FAST_PATH = 1, RC_OPT_WIDE_LAZY_QRCP = 2, RC_OPT_WIDE_COOP_QRCP = 3, RC_OPT_POWER_ITERATION_FIXED = 4, RC_OPT_FORK_BRANCHES = 5,
-       RC_OPT_BLOCKED_QRCP = 6, RC_OPT_CONCURRENCY_HINT = 7 };
+       RC_OPT_BLOCKED_QRCP = 6, RC_OPT_CONCURRENCY_HINT = 7, RC_OPT_COOP_PANEL = 8 };
 rc_status rc_set_option(rc_context *ctx, int32_t option, int64_t value);
 /* Health word (read and cleared), OR of: 1 non-positive Cholesky pivot, 2 first CholeskyQR pass too far from orthonormal
  * (both: tall-skinny fast path inside a graph, where no fallback is possible), 4 cooperative short-wide QR could not get

@@ -24,6 +24,7 @@ RC_OPT_POWER_ITERATION_FIXED = 4
 RC_OPT_FORK_BRANCHES = 5
 RC_OPT_BLOCKED_QRCP = 6
 RC_OPT_CONCURRENCY_HINT = 7
+RC_OPT_COOP_PANEL = 8
 RC_OK, RC_LINALG_ERROR, RC_COMPRESSION_ERROR, RC_LAYOUT_ERROR, RC_PIVOTED_QR_ERROR, RC_INVALID_ARGUMENT, RC_RUNTIME_ERROR = range(7)
 
 

@@ -593,12 +593,12 @@ __global__ __launch_bounds__(256) void k_qrb_build_vp_pos(Mat<T> w, int j0, cons
 // ---------------------------------------------------------------------------
 // panel end, one thread per physical column:
 //   pivoted columns        : F row = 0 (the block update must not touch them)
-//   candidates             : nothing (F row, rows of R and norms were kept current by the steps)
+//   candidates             : nothing (F row, rows of R and norms were kept current by the steps); F row = 0 after a cooperative panel
 //   every other column     : F(c, :) = Y(:, c)^T T, rows j0 .. j0+kb-1 (= rows of R), kb sequential norm down-dates
 // ---------------------------------------------------------------------------
 template <typename T>
 __global__ __launch_bounds__(256) void k_qrb_finish(Mat<T> w, int j0, int kb, const int *pos, const unsigned char *is_cand, T *vn1, const T *vn2, T *Fm,
-                                                    const T *Y, int64_t ldy, const T *Tm, Mat<T> vp, int *flag) {
+                                                    const T *Y, int64_t ldy, const T *Tm, Mat<T> vp, int *flag, int coop) {
     __shared__ T Tl[kNB * kNB], Vl[kNB * kNB];
     for (int e = threadIdx.x; e < kNB * kNB; e += 256) {
         const int r = e % kNB, q = e / kNB;  // element (r, q)
@@ -609,7 +609,8 @@ __global__ __launch_bounds__(256) void k_qrb_finish(Mat<T> w, int j0, int kb, co
     const int64_t c = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (c >= w.cols) return;
     T *frow = Fm + c * kNB;
-    if (pos[c] < j0 + kb) {
+    // (the candidates of a cooperative panel are already up to date: no F row either)
+    if (pos[c] < j0 + kb || (coop && is_cand[c])) {
 #pragma unroll
         for (int t = 0; t < kNB; ++t) frow[t] = 0;
         return;
@@ -677,6 +678,440 @@ __global__ __launch_bounds__(256) void k_qrb_renorm(Mat<T> w, int row0, int all,
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Cooperative panel: the steps of a panel in ONE launch, the candidates resident in registers.
+//
+// G workgroups of 8 waves; wave (wg, wv) owns candidate ci = 8 wg + wv and keeps rows j0 .. m-1 of its column in registers
+// (lane l holds rows VW l + 64 VW e + q, VW = 16 bytes of elements) for the whole panel, so the candidate slab is read once
+// and written once per panel and a step costs ONE grid barrier instead of two kernel boundaries.  The columns are kept UP
+// TO DATE (every reflector is applied to every unpivoted candidate right away, as ?laqp2 does), so there is no F matrix
+// for the candidates and a norm that loses its accuracy is recomputed on the spot from the registers instead of ending the
+// panel.  Per step (k_wq_coop's protocol, kernels_wqcoop.hip):
+//   A  every workgroup posts its best unpivoted candidate -- norm, position, candidate index, the column itself -- to its
+//      slot (write-through stores), then a header whose words carry the step number
+//   -- grid barrier = wave 0 polls the G headers until all carry this step's number --
+//   B  every workgroup agrees on the pivot (largest norm, first position on ties) and on the stop test (best candidate no
+//      longer above tau), fetches the winning column into LDS and generates the reflector redundantly (?larfg)
+//   C  every wave applies it to its column (v from LDS), down-dates its norm (?laqp2 formulas), and the waves that own
+//      EARLIER pivots of the panel record v_t^T v_k, from which the panel's T factor (?larft) is built afterwards
+// Nothing global is modified before the last step has completed: the permutation changes of the non-candidates are
+// kept in an overlay by workgroup 0 and flushed at the end, so a launch that had to give up (co-residency time-out, more
+// candidates than waves) leaves the panel untouched and the host runs it through the step kernels instead.
+// ---------------------------------------------------------------------------------------------------------------------
+template <typename T>
+struct QrbCoopArgs {
+    Mat<T> w;
+    int j0, nbp;
+    QrbPanel<T> P;              // cand, cpos[0] (initial positions), cvn (initial norms), vn2, st, tsc, tau, jpvt, pos
+    T *vn1, *vn2;               // by physical column
+    unsigned long long *hdr;    // [2][G][5]
+    T *cols;                    // [2][G][mpad]
+    int mpad;
+    T *D;                       // kNB x kNB: D[t + k * kNB] = v_t^T v_k  (t < k)
+    unsigned *sync;             // [0] finished-workgroup counter, [1] abort
+    unsigned *sem;
+    unsigned need;              // units of the device budget to release
+};
+
+__device__ inline void qc_st(double *p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ inline double qc_ld(const double *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+// NE vectors of VW = 16 / sizeof(T) rows per lane: 64 VW NE rows at most
+#ifdef RC_QRC_TIMING
+__device__ unsigned long long g_qrc_dbg[8];
+#endif
+template <typename T, int NE>
+__global__ __launch_bounds__(512) void k_qrb_coop(QrbCoopArgs<T> a) {
+    constexpr int VW = 16 / (int)sizeof(T);
+    constexpr int NW = 8;
+    constexpr int ROWS = 64 * VW * NE;
+    constexpr int kNoInt = 0x7fffffff;
+    constexpr int kSpin = 1 << 22;
+    typedef unsigned long long u64;
+    __shared__ __attribute__((aligned(16))) T vv[ROWS];   // the reflector
+    __shared__ T sh_part[NW], sh_alpha;
+    __shared__ double sh_v[NW];
+    __shared__ int sh_p[NW], sh_j[NW];
+    __shared__ int bc[6];
+    __shared__ int sh_exit;
+    __shared__ int ov_pos[kNB], ov_col[kNB], ov_n;
+    // (wave-uniform values are forced into scalar registers: the per-wave roles below must compile to scalar branches, not
+    // to exec-masked selects that keep two copies of the register-resident column alive)
+    const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int G = gridDim.x, wg = blockIdx.x;
+    const int j0 = a.j0;
+    const int rows = (int)a.w.rows - j0;  // <= ROWS (host)
+    QrbState *st = a.P.st;
+    unsigned *done = a.sync, *abortw = a.sync + 1;
+    const unsigned ab0 = __hip_atomic_load(abortw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (ab0 == 2u) {  // the gate gave up: no budget is held
+        if (wg == 0 && tid == 0) st->pad0 = 3;
+        return;
+    }
+    const int ncand = st->ncand;
+    const bool too_many = ncand > NW * G;
+    bool aborted = ab0 != 0u || too_many;
+    if (tid == 0) { sh_exit = 0; ov_n = 0; }
+
+    const int ci = wg * NW + wv;
+    const bool have = __builtin_amdgcn_readfirstlane((int)(ci < ncand && !aborted)) != 0;
+    const int c = have ? a.P.cand[ci] : 0;
+    T x[NE][VW];
+    {
+        const T *col = a.w.p + (int64_t)c * a.w.cs + j0;
+#pragma unroll
+        for (int e = 0; e < NE; ++e)
+#pragma unroll
+            for (int q = 0; q < VW; ++q) {
+                const int r = VW * lane + 64 * VW * e + q;
+                x[e][q] = (have && r < rows) ? col[r] : (T)0;
+            }
+    }
+    int mypos = __builtin_amdgcn_readfirstlane(have ? a.P.cpos[0][ci] : kNoInt);
+    T vn1 = have ? a.P.cvn[ci] : (T)0, vn2 = have ? a.P.vn2[c] : (T)0;
+    bool renormed = false;
+    const T lim = a.P.tsc[0] * ((T)1 + (T)4 * NumB<T>::tol3z());
+    const int have_noncand = st->have_noncand;
+    __syncthreads();
+
+    // per-phase s_memtime totals of workgroup 0 (diagnostic build only: -DRC_QRC_TIMING, tools/qrc_timing.py)
+#ifdef RC_QRC_TIMING
+    unsigned long long tph[6] = {0, 0, 0, 0, 0, 0}, tlast;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tlast)::"memory");
+#define RC_QTICK(k)                                                                       \
+    {                                                                                     \
+        unsigned long long now_;                                                          \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(now_)::"memory");   \
+        tph[k] += now_ - tlast;                                                           \
+        tlast = now_;                                                                     \
+    }
+#else
+#define RC_QTICK(k)
+#endif
+    int kb = 0, stop_tau = 0;
+    for (int jj = 0; jj < a.nbp && !aborted; ++jj) {
+        const int j = j0 + jj, par = jj & 1;
+        // (opaque copy of `rows` per step: keeps the compiler from hoisting one row-index register and one mask per
+        // element of the column out of this loop; lane-constant parts are written as VW * lane < scalar)
+        int rows_v = rows;
+        asm volatile("" : "+s"(rows_v));
+        const int l0 = VW * lane;
+        // ---- A: the workgroup's best unpivoted candidate ----------------------------------------------------------
+        if (lane == 0) {
+            const bool speak = have && mypos >= j;
+            double b = speak ? fabs((double)vn1) : -1.0;
+            if (speak && !(b >= 0.0)) b = -0.5;  // NaN norms are taken last
+            sh_v[wv] = b;
+            sh_p[wv] = speak ? mypos : kNoInt;
+            sh_j[wv] = (have && mypos == j) ? ci : -1;
+        }
+        __syncthreads();
+        RC_QTICK(0)
+        double lb = -1.0;
+        int lp = kNoInt, lc = -1, lj = -1;
+#pragma unroll
+        for (int k2 = 0; k2 < NW; ++k2) {
+            const double v2 = sh_v[k2];
+            const int p2 = sh_p[k2];
+            if (p2 != kNoInt && (lc < 0 || v2 > lb || (v2 == lb && p2 < lp))) { lb = v2; lp = p2; lc = wg * NW + k2; }
+            lj = sh_j[k2] > lj ? sh_j[k2] : lj;
+        }
+        if (__builtin_amdgcn_readfirstlane((int)(lc == ci && have))) {  // this wave's column is the workgroup's candidate: post it
+            T *slot = a.cols + ((size_t)par * G + wg) * a.mpad;
+#pragma unroll
+            for (int e = 0; e < NE; ++e) {
+                const int r = VW * lane + 64 * VW * e;
+                if (l0 < rows_v - 64 * VW * e) {  // rows beyond the matrix inside the last vector are zeros
+                    if constexpr (sizeof(T) == 8) {
+                        qc_st(reinterpret_cast<double *>(slot + r), (double)x[e][0]);
+                        qc_st(reinterpret_cast<double *>(slot + r + 1), (double)x[e][1]);
+                    } else {
+                        qc_st(reinterpret_cast<double *>(slot + r), __hiloint2double(__float_as_int((float)x[e][1]), __float_as_int((float)x[e][0])));
+                        qc_st(reinterpret_cast<double *>(slot + r + 2), __hiloint2double(__float_as_int((float)x[e][3]), __float_as_int((float)x[e][2])));
+                    }
+                }
+            }
+        }
+        // the column's write-through stores have completed (the barrier waits for vmcnt(0)) before the header is written
+        __syncthreads();
+        RC_QTICK(1)
+        if (wv == 0) {
+            const u64 tag = (unsigned)(jj + 1);
+            if (lane == 0) {
+                u64 *h = a.hdr + ((size_t)par * G + wg) * 5;
+                const u64 nb = (u64)__double_as_longlong(lc >= 0 ? lb : -1.0);
+                __hip_atomic_store(h + 0, (nb & 0xffffffff00000000ull) | tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(h + 1, (nb << 32) | tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(h + 2, ((u64)(unsigned)(lc >= 0 ? lp : kNoInt) << 32) | tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(h + 3, ((u64)(unsigned)lc << 32) | tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(h + 4, ((u64)(unsigned)lj << 32) | tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            // ---- grid barrier + pivot agreement: poll the G headers (one per lane) until all carry this step's tag
+            double hb = -2.0;
+            int hp = kNoInt, hc = -1, hj = -1;
+            bool ab = false;
+            for (int it = 0;; ++it) {
+                bool ok = true;
+                hb = -2.0; hp = kNoInt; hc = -1; hj = -1;
+                if (lane < G) {
+                    const u64 *h = a.hdr + ((size_t)par * G + lane) * 5;
+                    const u64 w0 = __hip_atomic_load(h + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), w1 = __hip_atomic_load(h + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT),
+                              w2 = __hip_atomic_load(h + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), w3 = __hip_atomic_load(h + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT),
+                              w4 = __hip_atomic_load(h + 4, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    ok = (unsigned)w0 == (unsigned)tag && (unsigned)w1 == (unsigned)tag && (unsigned)w2 == (unsigned)tag && (unsigned)w3 == (unsigned)tag &&
+                         (unsigned)w4 == (unsigned)tag;
+                    hb = __longlong_as_double((long long)((w0 & 0xffffffff00000000ull) | (w1 >> 32)));
+                    hp = (int)(w2 >> 32);
+                    hc = (int)(w3 >> 32);
+                    hj = (int)(w4 >> 32);
+                }
+                if (__all(ok)) break;
+                if (it > kSpin || ((it & 31) == 31 && __any(__hip_atomic_load(abortw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u))) { ab = true; break; }
+                __builtin_amdgcn_s_sleep(1);
+            }
+            const double mx = wave_max_dpp(hc >= 0 ? hb : -2.0);
+            const int wp = wave_min_dpp((hc >= 0 && hb == mx) ? hp : kNoInt);
+            const u64 mask = __ballot(hc >= 0 && hb == mx && hp == wp);
+            const int src = mask ? __ffsll((long long)mask) - 1 : 0;
+            const int wc = mask ? __builtin_amdgcn_readlane(hc, src) : -1;
+            const int cj = wave_max_dpp(hj);
+            if (lane == 0) {
+                // stop: no unpivoted candidate left, or the best one no longer exceeds every excluded column
+                // (the first step of a panel always proceeds: the first maximum over all columns is a candidate by construction)
+                const int why_tau = (wc >= 0 && jj > 0 && have_noncand && !((T)mx > lim)) ? 1 : 0;
+                const int stop = (wc < 0 || why_tau) ? 1 : 0;
+                if (ab) __hip_atomic_store(abortw, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                sh_exit = ab ? 1 : 0;
+                bc[0] = wc; bc[1] = wp; bc[2] = cj; bc[3] = stop; bc[4] = why_tau;
+            }
+        }
+        __syncthreads();
+        RC_QTICK(2)
+        if (sh_exit) { aborted = true; break; }
+        const int wc = __builtin_amdgcn_readfirstlane(bc[0]), wp = __builtin_amdgcn_readfirstlane(bc[1]), cj = __builtin_amdgcn_readfirstlane(bc[2]);
+        if (bc[3]) { stop_tau = bc[4]; break; }
+        // ---- B: the winning column (complete before its header was posted) -> registers of the whole workgroup, ?larfg from the
+        //         workgroup's partial sums (identical arithmetic in every workgroup), the reflector -> LDS ---------------------------
+        constexpr int NF = (ROWS * (int)sizeof(T) / 8 + 511) / 512;  // 8-byte words of the column per thread
+        double cw8[NF];
+        {
+            const double *src = reinterpret_cast<const double *>(a.cols + ((size_t)par * G + (wc / NW)) * a.mpad);
+            const int nd = ((rows_v + VW - 1) / VW) * 2;  // whole 16-byte vectors were posted (zeros beyond the matrix)
+#pragma unroll
+            for (int u = 0; u < NF; ++u) {
+                const int i = tid + 512 * u;
+                cw8[u] = i < nd ? qc_ld(src + i) : 0.0;
+            }
+        }
+        T tj = 0, beta, scal = 0;
+        {
+            T part = 0;
+#pragma unroll
+            for (int u = 0; u < NF; ++u) {
+                const int i = tid + 512 * u;
+                if constexpr (sizeof(T) == 8) {
+                    const T xv = (T)cw8[u];
+                    if (i > jj) part = fma(xv, xv, part);
+                    if (i == jj) sh_alpha = xv;
+                } else {
+                    const T x0 = (T)__int_as_float(__double2loint(cw8[u])), x1 = (T)__int_as_float(__double2hiint(cw8[u]));
+                    if (2 * i > jj) part = fma(x0, x0, part);
+                    if (2 * i + 1 > jj) part = fma(x1, x1, part);
+                    if (2 * i == jj) sh_alpha = x0;
+                    if (2 * i + 1 == jj) sh_alpha = x1;
+                }
+            }
+            part = wave_sum_dpp(part);
+            if (lane == 0) sh_part[wv] = part;
+        }
+        __syncthreads();
+        RC_QTICK(3)
+        {
+            T ss = 0;
+#pragma unroll
+            for (int k2 = 0; k2 < NW; ++k2) ss += sh_part[k2];
+            const T xnorm = sqrt(ss);
+            const T alpha = sh_alpha;
+            beta = alpha;
+            if (xnorm != (T)0) {
+                const T aa = fabs(alpha);
+                const T wmax = aa > xnorm ? aa : xnorm, zmin = aa > xnorm ? xnorm : aa;
+                const T zr = zmin / wmax;
+                beta = -copysign(wmax * sqrt(fma(zr, zr, (T)1)), alpha);
+                tj = (beta - alpha) / beta;
+                scal = (T)1 / (alpha - beta);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < NF; ++u) {
+            const int i = tid + 512 * u;
+            if (i < ROWS * (int)sizeof(T) / 8) {
+                if constexpr (sizeof(T) == 8) {
+                    vv[i] = i < jj ? (T)0 : i == jj ? (T)1 : (T)cw8[u] * scal;
+                } else {
+                    const T x0 = (T)__int_as_float(__double2loint(cw8[u])), x1 = (T)__int_as_float(__double2hiint(cw8[u]));
+                    vv[2 * i] = 2 * i < jj ? (T)0 : 2 * i == jj ? (T)1 : x0 * scal;
+                    vv[2 * i + 1] = 2 * i + 1 < jj ? (T)0 : 2 * i + 1 == jj ? (T)1 : x1 * scal;
+                }
+            }
+        }
+        __syncthreads();
+        RC_QTICK(4)
+        // ---- C: apply, down-date, bookkeeping -------------------------------------------------------------------------
+        if (have) {
+            // f32: the reflector stays in registers between the dot product and the update (one LDS pass); f64: two passes of
+            // four vectors at a time (register budget)
+            constexpr bool VREG = sizeof(T) == 4;
+            T vr[VREG ? NE : 1][VW];
+            T dot = 0;
+#pragma unroll
+            for (int e = 0; e < NE; ++e) {
+#pragma unroll
+                for (int q = 0; q < VW; ++q) {
+                    const T vq = vv[l0 + 64 * VW * e + q];
+                    if (VREG) vr[VREG ? e : 0][q] = vq;
+                    dot = fma(vq, x[e][q], dot);
+                }
+                if (!VREG && (e & 3) == 3) __builtin_amdgcn_sched_barrier(0);  // at most four LDS vectors in flight
+            }
+            dot = wave_sum_dpp(dot);
+            const int role = __builtin_amdgcn_readfirstlane(ci == wc ? 1 : (mypos < j ? 2 : 3));
+            if (role == 1) {
+                // pivot column: R(j, j) = beta, the reflector below the diagonal (?geqp3 format); rows above keep R
+                mypos = j;
+                if (lane == 0) { st->piv[jj] = c; a.P.tau[j] = tj; }  // (the owner knows its physical column: no load on anybody's critical path)
+#pragma unroll
+                for (int e = 0; e < NE; ++e) {
+#pragma unroll
+                    for (int q = 0; q < VW; ++q) {
+                        const T vq = VREG ? vr[VREG ? e : 0][q] : vv[l0 + 64 * VW * e + q];  // zero beyond the matrix, like the column
+                        if (e > 0) x[e][q] = vq;
+                        else if (l0 + q == jj) x[e][q] = beta;
+                        else if (l0 + q > jj) x[e][q] = vq;
+                    }
+                    if (!VREG && (e & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+                }
+            } else if (role == 2) {
+                // an earlier pivot of this panel: rows >= jj of its column hold its reflector, so dot = v_t^T v_k
+                if (lane == 0) a.D[(mypos - j0) + jj * kNB] = dot;
+            } else {
+                if (ci == cj && wp != j) mypos = wp;  // (scalar)
+                if (tj != (T)0) {
+                    const T f = tj * dot;
+#pragma unroll
+                    for (int e = 0; e < NE; ++e) {
+#pragma unroll
+                        for (int q = 0; q < VW; ++q) x[e][q] = fma(-f, VREG ? vr[VREG ? e : 0][q] : vv[l0 + 64 * VW * e + q], x[e][q]);
+                        if (!VREG && (e & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+                    }
+                }
+                // row jj of this column = its entry of row j of R: lane jj / VW, component jj % VW of register vector 0
+                T aj = 0;
+#pragma unroll
+                for (int q = 0; q < VW; ++q) aj = (jj % VW == q) ? x[0][q] : aj;
+                aj = __shfl(aj, jj / VW, 64);
+                if (vn1 != (T)0) {  // ?laqp2 down-date
+                    const T t = fabs(aj) / vn1;
+                    T temp = (T)1 - t * t;
+                    temp = temp > (T)0 ? temp : (T)0;
+                    const T r2 = vn1 / vn2;
+                    if (temp * r2 * r2 <= NumB<T>::tol3z()) {
+                        T ssl = 0;
+#pragma unroll
+                        for (int e = 0; e < NE; ++e)
+#pragma unroll
+                            for (int q = 0; q < VW; ++q)
+                                if (e > 0 || l0 + q > jj) ssl = fma(x[e][q], x[e][q], ssl);  // rows beyond the matrix hold zeros
+                        ssl = wave_sum_dpp(ssl);
+                        vn1 = vn2 = (jj < rows_v - 1) ? sqrt(ssl) : (T)0;
+                        renormed = true;
+                    } else {
+                        vn1 = vn1 * sqrt(temp);
+                    }
+                }
+            }
+        }
+        if (wg == 0 && tid == 0) {
+            if (cj < 0 && wp != j) {
+                // the column at position j is not a candidate: it moves to the pivot's old position (overlay; flushed at the end)
+                int oldc = -1, slot = -1;
+                for (int i = 0; i < ov_n; ++i)
+                    if (ov_pos[i] == j) { oldc = ov_col[i]; slot = i; }
+                if (oldc < 0) { oldc = (int)a.P.jpvt[j]; slot = ov_n; ov_n = ov_n + 1; }
+                ov_pos[slot] = wp;
+                ov_col[slot] = oldc;
+            }
+        }
+        kb = jj + 1;
+        RC_QTICK(5)
+    }
+#undef RC_QTICK
+#ifdef RC_QRC_TIMING
+    if (wg == 0 && tid == 0)
+        for (int k2 = 0; k2 < 6; ++k2) g_qrc_dbg[k2] = tph[k2];
+#endif
+
+    // ---- the panel is done: columns, norms and the permutation go back -------------------------------------------------------
+    if (!aborted) {
+        if (have) {
+            T *col = a.w.p + (int64_t)c * a.w.cs + j0;
+#pragma unroll
+            for (int e = 0; e < NE; ++e)
+#pragma unroll
+                for (int q = 0; q < VW; ++q) {
+                    const int r = VW * lane + 64 * VW * e + q;
+                    if (r < rows) col[r] = x[e][q];
+                }
+            if (lane == 0) {
+                a.vn1[c] = vn1;
+                if (renormed) a.vn2[c] = vn2;
+                a.P.pos[c] = mypos;
+                a.P.jpvt[mypos] = c;
+            }
+        }
+        if (wg == 0 && tid == 0) {
+            for (int i = 0; i < ov_n; ++i) { a.P.jpvt[ov_pos[i]] = ov_col[i]; a.P.pos[ov_col[i]] = ov_pos[i]; }
+            st->stopped = kb < a.nbp ? 1 : 0;
+            st->kb = kb;
+            st->stop_tau = stop_tau;
+            st->lsticc = 0;
+            st->pad0 = 1;  // the cooperative panel completed
+        }
+    } else if (wg == 0 && tid == 0) {
+        st->pad0 = too_many ? 2 : 3;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        const unsigned old = __hip_atomic_fetch_add(done, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+        if (old == (unsigned)G - 1u) __hip_atomic_fetch_sub(a.sem, a.need, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
+// T factor of a cooperative panel from the recorded v_t^T v_k (?larft, forward / columnwise): T(0:k, k) = -tau_k T(0:k, 0:k) d(0:k, k)
+template <typename T>
+__global__ __launch_bounds__(64) void k_qrb_build_t(const T *D, const T *tau, int j0, int kb, T *Tm) {
+    __shared__ T Tl[kNB * kNB], Dl[kNB * kNB], taul[kNB];
+    const int i = threadIdx.x;
+    for (int e = i; e < kNB * kNB; e += 64) {
+        Tl[e] = 0;
+        const int t = e % kNB, k = e / kNB;
+        Dl[e] = (t < k && k < kb) ? D[e] : (T)0;
+    }
+    if (i < kNB) taul[i] = i < kb ? tau[j0 + i] : (T)0;
+    __syncthreads();
+    for (int k = 0; k < kb; ++k) {
+        const T tk = taul[k];
+        if (i < k) {
+            T acc = 0;
+            for (int t = i; t < k; ++t) acc = fma(Tl[i + t * kNB], Dl[t + k * kNB], acc);
+            Tl[i + k * kNB] = -tk * acc;
+        }
+        if (i == k) Tl[k + k * kNB] = tk;
+        __syncthreads();
+    }
+    for (int e = i; e < kNB * kNB; e += 64) Tm[e] = Tl[e];
+}
+
 static int env_int_b(const char *name, int dflt) {
     const char *e = getenv(name);
     return e ? atoi(e) : dflt;
@@ -686,6 +1121,29 @@ template <typename T>
 bool geqp3_blocked_supported(int64_t m, int64_t n, int64_t kmax) {
     static const int on = env_int_b("RC_QRCP_BLOCKED", 1);
     return on && m >= 128 && n >= 128 && kmax >= 8 && n < (int64_t)1 << 30 && m < (int64_t)1 << 30;
+}
+
+constexpr int kCoopWgs = 64;  // workgroups of a cooperative panel at most (8 candidates each; one header per lane of the polling wave)
+template <typename T> constexpr int coop_ne_big() { return sizeof(T) == 8 ? 24 : 16; }  // f64: 96 doubles of slab per lane is what fits beside the working set
+template <typename T> constexpr int coop_rows_cap() { return 64 * (16 / (int)sizeof(T)) * coop_ne_big<T>(); }  // f32: 4096 rows, f64: 3072
+
+// units of the device-wide cooperative budget (half CUs) one workgroup of the kernel costs
+template <typename K>
+static unsigned coop_units_per_wg(K kern) {
+    int nb = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void *>(kern), 512, 0) != hipSuccess) { (void)hipGetLastError(); nb = 1; }
+    return nb >= 2 ? 1u : 2u;
+}
+
+template <typename T>
+static void qrb_coop_launch(rc_context *c, QrbCoopArgs<T> a, int g, int rows) {
+    constexpr int NE_BIG = coop_ne_big<T>(), NE_SMALL = NE_BIG / 4;
+    const bool small = rows <= 64 * (16 / (int)sizeof(T)) * NE_SMALL;
+    static const unsigned units_big = coop_units_per_wg(k_qrb_coop<T, NE_BIG>), units_small = coop_units_per_wg(k_qrb_coop<T, NE_SMALL>);
+    a.need = (unsigned)g * (small ? units_small : units_big);
+    coop_gate_launch(c, a.need, a.sync, a.hdr, 2 * g * 5);
+    if (small) hipLaunchKernelGGL((k_qrb_coop<T, NE_SMALL>), dim3((unsigned)g), dim3(512), 0, c->stream, a);
+    else hipLaunchKernelGGL((k_qrb_coop<T, NE_BIG>), dim3((unsigned)g), dim3(512), 0, c->stream, a);
 }
 
 // One factorization as a resumable job: issue() enqueues a panel's kernels and the read-back of its state, finish() -- once
@@ -710,6 +1168,12 @@ struct BlockedQrcpJob {
     int nbp = 0;
     struct PanelRec { int64_t j0; int kb; T *tm; };
     std::vector<PanelRec> panels;  // finished panels with their T factors (block form-Q)
+    // cooperative panels (k_qrb_coop)
+    QrbCoopArgs<T> coop;
+    bool coop_ready = false, coop_issued = false;
+    int coop_fallbacks = 0;
+    int64_t cw_issued = 0;
+    unsigned grid_a = 0, grid_c = 0;
 };
 
 template <typename T>
@@ -759,6 +1223,21 @@ BlockedQrcpJob<T> *qrb_begin(rc_context *c, Mat<T> w, int64_t kmax, int64_t *jpv
     static const int cand_mb = env_int_b("RC_QRCP_CAND_MB", 8);
     J->cwant = std::max<int64_t>(4 * kNB, ((int64_t)cand_mb << 20) / (int64_t)(sizeof(T) * (size_t)std::max<int64_t>(m, 1)));
     if (cand_mb <= 0) J->cwant = n;  // plain ?laqps
+    // cooperative panels: header / candidate slots of up to kCoopWgs workgroups, the recorded v_t^T v_k
+    static const int coop_on = env_int_b("RC_QRCP_COOP", 1);
+    if (coop_on && c->opt_coop_panel && cand_mb > 0) {
+        QrbCoopArgs<T> &a = J->coop;
+        a.w = w;
+        a.P = P;
+        a.vn1 = J->vn1; a.vn2 = J->vn2;
+        a.mpad = coop_rows_cap<T>();
+        a.hdr = c->alloc<unsigned long long>((size_t)2 * kCoopWgs * 5);
+        a.cols = c->alloc<T>((size_t)2 * kCoopWgs * a.mpad);
+        a.D = c->alloc<T>((size_t)kNB * kNB);
+        a.sync = c->alloc<unsigned>(4);
+        a.sem = coop_semaphore_of(c->device);
+        J->coop_ready = true;
+    }
     return J;
 }
 
@@ -767,7 +1246,7 @@ static void qrb_issue_launches(BlockedQrcpJob<T> *J, int nbp, int64_t cw, unsign
     rc_context *c = J->c;
     const int64_t n = J->n, j0 = J->j0;
     hipLaunchKernelGGL(k_qrb_select<T>, dim3(1), dim3(1024), 0, c->stream, (int)n, (int)j0, (int)cw, J->pos, J->vn1, J->cand, J->is_cand, J->st, J->tsc, J->P.cpos[0],
-                       J->P.cvn);
+                       J->P.cvn);  // (also resets the panel state)
     for (int k = 0; k < nbp; ++k) {
         hipLaunchKernelGGL(k_qrb_step_a<T>, dim3(grid_a), dim3(256), 0, c->stream, J->w, (int)j0, k, J->P);
         hipLaunchKernelGGL(k_qrb_step_c<T>, dim3(grid_c), dim3(256), 0, c->stream, J->w, (int)j0, k, (int)grid_a, J->vec_ok, J->P);
@@ -787,6 +1266,23 @@ void qrb_issue(BlockedQrcpJob<T> *J) {
     const int64_t cbound = std::min<int64_t>(n - j0, 2 * cw);
     const unsigned grid_a = (unsigned)std::max<int64_t>(4, std::min<int64_t>(std::min<int64_t>(64, cdivb(m - j0, 64)), 65536 / std::max<int64_t>(cbound, 1)));
     const unsigned grid_c = (unsigned)std::max<int64_t>(1, std::min<int64_t>(cbound, 4096));
+    J->grid_a = grid_a; J->grid_c = grid_c; J->cw_issued = cw; J->coop_issued = false;
+    // Cooperative panel (one launch for all steps, candidates in registers) when the active rows fit the registers of a
+    // wave; fewer candidates are requested than the launch has waves, because ties at the threshold all become candidates
+    if (J->coop_ready && J->coop_fallbacks < 4 && m - j0 <= coop_rows_cap<T>() && m - j0 >= 8) {
+        const int64_t cw_c = std::min<int64_t>(cw, 8 * kCoopWgs - 32);
+        const int g = (int)std::min<int64_t>(kCoopWgs, cdivb(cw_c + std::max<int64_t>(8, cw_c / 16), 8));
+        hipLaunchKernelGGL(k_qrb_select<T>, dim3(1), dim3(1024), 0, c->stream, (int)n, (int)j0, (int)cw_c, J->pos, J->vn1, J->cand, J->is_cand, J->st, J->tsc, J->P.cpos[0],
+                           J->P.cvn);
+        QrbCoopArgs<T> a = J->coop;
+        a.j0 = (int)j0;
+        a.nbp = nbp;
+        qrb_coop_launch<T>(c, a, g, (int)(m - j0));
+        RC_HIP(hipMemcpyAsync(J->host_st, J->st, sizeof(QrbState), hipMemcpyDeviceToHost, c->stream));
+        J->coop_issued = true;
+        J->cw_issued = cw_c;
+        return;
+    }
     // A panel is ~65 dependent launches at ~3.5 us of host time each: replay them from a hipGraph, cached on the context
     // under everything the launches bake in (the arena hands out the same addresses for the same call sequence, so a
     // host that compresses many same-shaped matrices replays).  Opt-in (RC_QRCP_GRAPH=1): measured on MI355X the replay does not
@@ -823,8 +1319,22 @@ void qrb_issue(BlockedQrcpJob<T> *J) {
 template <typename T>
 bool qrb_finish(BlockedQrcpJob<T> *J) {
     rc_context *c = J->c;
-    const QrbState h = *J->host_st;
+    QrbState h = *J->host_st;
     const int64_t m = J->m, n = J->n, j0 = J->j0;
+    bool coop = false;
+    if (J->coop_issued) {
+        if (h.pad0 == 1) {
+            coop = true;
+        } else {
+            // the cooperative launch left the panel untouched (2: more candidates than its waves, 3: co-residency time-out):
+            // run the panel through the step kernels (rare; costs one more wait)
+            J->coop_fallbacks += (h.pad0 == 2) ? 1 : 4;
+            qrb_issue_launches(J, J->nbp, J->cw_issued, J->grid_a, J->grid_c);
+            RC_HIP(hipStreamSynchronize(c->stream));
+            h = *J->host_st;
+        }
+        J->coop_issued = false;
+    }
     const int kb = h.stopped ? h.kb : J->nbp;
     RC_REQUIRE(kb >= 1 && kb <= J->nbp, RC_PIVOTED_QR_ERROR, "geqp3_blocked: panel at %lld made %d steps", (long long)j0, kb);
     const int64_t rows = m - j0;
@@ -837,9 +1347,10 @@ bool qrb_finish(BlockedQrcpJob<T> *J) {
         Mat<T> ym = rowmajor(J->Y, kb, n, J->ldy);
         gemm<T>(c, 1, vpp.t(), w.sub(j0, rows, 0, n), 0, ym);
     }
-    hipLaunchKernelGGL(k_qrb_scatter<T>, dim3((unsigned)cdivb(std::max(h.ncand, 1), 256)), dim3(256), 0, c->stream, w, (int)j0, kb, J->P, J->vn1);
+    if (coop) hipLaunchKernelGGL(k_qrb_build_t<T>, dim3(1), dim3(64), 0, c->stream, J->coop.D, J->tau, (int)j0, kb, J->Tm);
+    else hipLaunchKernelGGL(k_qrb_scatter<T>, dim3((unsigned)cdivb(std::max(h.ncand, 1), 256)), dim3(256), 0, c->stream, w, (int)j0, kb, J->P, J->vn1);
     hipLaunchKernelGGL(k_qrb_finish<T>, dim3((unsigned)cdivb(n, 256)), dim3(256), 0, c->stream, w, (int)j0, kb, J->pos, J->is_cand, J->vn1, J->vn2, J->Fm, J->Y, J->ldy,
-                       J->Tm, vpp, J->flag);
+                       J->Tm, vpp, J->flag, coop ? 1 : 0);
     if (!last && rows - kb > 0) {
         // block update of everything below the panel, written as the transposed product so that the lanes of the
         // MFMA accumulator run along the column-major matrix' contiguous dimension:
@@ -860,7 +1371,7 @@ bool qrb_finish(BlockedQrcpJob<T> *J) {
         J->panels.push_back({j0, kb, tsave});
     }
     static const int dbg = env_int_b("RC_QRCP_DEBUG", 0);
-    if (dbg) fprintf(stderr, "qrb panel j0=%lld kb=%d/%d ncand=%d noncand=%d lsticc=%d stop_tau=%d cwant=%lld\n", (long long)j0, kb, J->nbp, h.ncand, h.have_noncand, h.lsticc, h.stop_tau, (long long)J->cwant);
+    if (dbg) fprintf(stderr, "qrb panel j0=%lld kb=%d/%d ncand=%d noncand=%d lsticc=%d stop_tau=%d cwant=%lld coop=%d\n", (long long)j0, kb, J->nbp, h.ncand, h.have_noncand, h.lsticc, h.stop_tau, (long long)J->cwant, coop ? 1 : 0);
     if (h.stop_tau && kb < J->nbp) J->cwant = std::min<int64_t>(n, kb < J->nbp / 2 ? J->cwant * 2 : J->cwant * 3 / 2);
     J->j0 += kb;
     return J->j0 >= J->kmax;
@@ -916,6 +1427,9 @@ void geqp3_blocked(rc_context *c, Mat<T> w, int64_t kmax, int64_t *jpvt, T *tau,
     if (!q_out.empty()) qrb_form_q(J, q_out);
 }
 
+#ifdef RC_QRC_TIMING
+extern "C" void rc_debug_qrc_timing(unsigned long long *out) { (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_qrc_dbg), 8 * sizeof(unsigned long long)); }
+#endif
 #define RC_INST_JOB(T)                                                                           \
     template BlockedQrcpJob<T> *qrb_begin<T>(rc_context *, Mat<T>, int64_t, int64_t *, T *);     \
     template void qrb_issue<T>(BlockedQrcpJob<T> *);                                             \

@@ -40,7 +40,8 @@ namespace rc {
 
 namespace {
 
-constexpr int kCoopBudgetCUs = 192;      // of 256: leaves room for everything that is not cooperative
+// The budget is counted in HALF compute units (a cooperative workgroup that leaves room for a second one on its CU costs
+// one unit, one that fills the CU two): three quarters of the device, the rest stays free for everything that is not cooperative.
 constexpr int kCoopMaxWgs = 128;
 constexpr int kSpinLimit = 1 << 22;      // ~ seconds
 
@@ -411,7 +412,7 @@ __global__ __launch_bounds__(512) void k_wq_coop(WqCoopArgs<T> a) {
     if (tid == 0) {
         if (aborted) atomicOr(a.flag, 4);
         const unsigned old = __hip_atomic_fetch_add(done, 1u, __ATOMIC_ACQ_REL, RC_AGENT);
-        if (old == (unsigned)G - 1u) __hip_atomic_fetch_sub(a.sem, (unsigned)G, __ATOMIC_RELAXED, RC_AGENT);
+        if (old == (unsigned)G - 1u) __hip_atomic_fetch_sub(a.sem, 2u * (unsigned)G, __ATOMIC_RELAXED, RC_AGENT);
     }
 }
 
@@ -428,6 +429,30 @@ static unsigned *coop_semaphore(int device) {
     return s;
 }
 void coop_prepare(int device) { (void)coop_semaphore(device); }
+unsigned *coop_semaphore_of(int device) { return coop_semaphore(device); }
+
+unsigned coop_budget_units(int device) {
+    static std::mutex mu;
+    static unsigned cached[64] = {};
+    std::lock_guard<std::mutex> lk(mu);
+    unsigned &b = cached[device & 63];
+    if (!b) {
+        int cus = 0;
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || cus <= 0) cus = 256;
+        const char *e = getenv("RC_COOP_BUDGET");  // in CUs (experiments)
+        const int v = e ? atoi(e) : 0;
+        b = (unsigned)(v >= 32 && v <= cus ? 2 * v : 2 * cus * 3 / 4);
+    }
+    return b;
+}
+
+// one-thread gate in front of a cooperative kernel: takes `need` units of the device-wide budget (released by the cooperative
+// kernel's last workgroup), clears the kernel's header words and its sync words
+void coop_gate_launch(rc_context *c, unsigned need, unsigned *sync, unsigned long long *hdr, int hdr_words) {
+    const unsigned budget = coop_budget_units(c->device);
+    RC_REQUIRE(need <= budget, RC_INVALID_ARGUMENT, "cooperative kernel needs %u units of a budget of %u", need, budget);
+    hipLaunchKernelGGL(k_coop_gate, dim3(1), dim3(256), 0, c->stream, coop_semaphore(c->device), need, budget, sync, hdr, hdr_words);
+}
 
 template <typename T>
 static void coop_shape(int64_t m, int64_t n, int *ne, int *cpg, int *cpw, int *g) {
@@ -472,8 +497,8 @@ void geqp3_wide_coop(rc_context *c, Mat<T> w, Mat<T> wf, int64_t kmax, int64_t *
     a.sync = c->alloc<unsigned>(4);
     a.sem = coop_semaphore(c->device);
     a.flag = flag;
-    static const int budget = [] { const char *e = getenv("RC_COOP_BUDGET"); const int v = e ? atoi(e) : 0; return v >= 32 && v <= 256 ? v : kCoopBudgetCUs; }();  // experiments
-    hipLaunchKernelGGL(k_coop_gate, dim3(1), dim3(256), 0, c->stream, a.sem, (unsigned)g, (unsigned)budget, a.sync, a.hdr, 2 * g * 5);
+    // 512 threads x up to 256 VGPRs: one workgroup fills its CU = 2 units each
+    coop_gate_launch(c, 2u * (unsigned)g, a.sync, a.hdr, 2 * g * 5);
 #define RC_COOP(NE_, CPG_) hipLaunchKernelGGL((k_wq_coop<T, NE_, CPG_>), dim3((unsigned)g), dim3(512), 0, c->stream, a)
     if (ne == 8) RC_COOP(8, 8);
     else if (ne == 16) RC_COOP(16, 4);

@@ -926,6 +926,7 @@ rc_status rc_set_option(rc_context *ctx, int32_t option, int64_t value) {
         case RC_OPT_POWER_ITERATION_FIXED: ctx->opt_power_fixed = value != 0; return RC_OK;
         case RC_OPT_FORK_BRANCHES: ctx->opt_fork = value != 0; return RC_OK;
         case RC_OPT_BLOCKED_QRCP: ctx->opt_blocked = value != 0; return RC_OK;
+        case RC_OPT_COOP_PANEL: ctx->opt_coop_panel = value != 0; return RC_OK;
         case RC_OPT_CONCURRENCY_HINT: ctx->opt_lanes = (int)std::max<int64_t>(1, std::min<int64_t>(value, 1024)); return RC_OK;
         default: ctx->last_error = "unknown option"; return RC_INVALID_ARGUMENT;
     }

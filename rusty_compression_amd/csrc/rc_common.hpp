@@ -123,6 +123,7 @@ struct rc_context {
     int opt_wide_coop = 1;  // short-wide pivoted QR as ONE cooperative register-resident kernel (0: multi-kernel paths)
     int opt_wide_lazy = 1;  // short-wide pivoted QR through the read-only lazy scheme (0: eager Householder chain)
     int opt_blocked = 1;    // general shapes: blocked ?laqps panels + GEMM block update (0: per-step Householder chain)
+    int opt_coop_panel = 1; // RC_OPT_COOP_PANEL: cooperative register-resident panels of the blocked QRCP
     int opt_lanes = 1;      // RC_OPT_CONCURRENCY_HINT: independent compressions the host keeps in flight on this device
     int *health = nullptr;
     int *health_word();
@@ -232,6 +233,10 @@ template <typename T> void geqp3_wide_lazy(rc_context *c, Mat<T> b, int64_t kmax
 template <typename T> bool wide_coop_supported(int64_t m, int64_t n);
 template <typename T> void geqp3_wide_coop(rc_context *c, Mat<T> w, Mat<T> wf, int64_t kmax, int64_t *jpvt, T *tau, int *flag);
 void coop_prepare(int device);
+// device-wide budget of the cooperative kernels, in half compute units (kernels_wqcoop.hip)
+unsigned *coop_semaphore_of(int device);
+unsigned coop_budget_units(int device);
+void coop_gate_launch(rc_context *c, unsigned need, unsigned *sync, unsigned long long *hdr, int hdr_words);
 // r(i, p) = (i <= p) ? w(i, jpvt[p]) : 0  for i < r.rows
 template <typename T> void extract_r(rc_context *c, Mat<T> w, const int64_t *jpvt, Mat<T> r);
 // qw (m x kq column-major) = H_0 ... H_{k-1} [I ; 0], reflector j stored in column jpvt[j] of w

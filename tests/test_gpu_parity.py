@@ -957,6 +957,57 @@ def test_blocked_qrcp_degenerate_inputs(dtype):
     assert rel(q @ r, x[:, ind]) <= (1e-12 if f64 else 2e-5) and np.abs(q.T @ q - np.eye(400)).max() <= (1e-12 if f64 else 2e-5)
 
 
+def _with_coop_panel(on, fn):
+    from rusty_compression_amd import _lib
+
+    ctx = _lib.default_context()
+    ctx.set_option(_lib.RC_OPT_COOP_PANEL, 1 if on else 0)
+    try:
+        return fn()
+    finally:
+        ctx.set_option(_lib.RC_OPT_COOP_PANEL, 1)
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+@pytest.mark.parametrize("shape", [(157, 520), (301, 700), (300, 400), (1021, 1300), (333, 2000)])
+def test_cooperative_panels_match_the_step_kernels_and_lapack(dtype, shape):
+    """The cooperative register-resident panel (k_qrb_coop) against the step kernels (RC_OPT_COOP_PANEL = 0) and ?geqp3: odd
+    row counts (the last 16-byte vector of a column is partly beyond the matrix), more columns than one launch has waves
+    (non-candidates take the Y = V^T A / T-factor route), fewer (every column a candidate), panels ended by the tau test."""
+    f64 = dtype == np.float64
+    rng = np.random.default_rng(shape[0] * 7 + shape[1])
+    a = o.random_approximate_low_rank_matrix(shape, 1.0, 1e-6 if f64 else 1e-3, rng, dtype)
+    k = min(shape)
+    oq, orr, oind = o.pivoted_qr(a)
+    want = stable_prefix(orr, dtype)
+    res = {}
+    for coop in (True, False):
+        q, r, ind = _with_coop_panel(coop, lambda: tuple(npy(t) for t in rc.pivoted_qr(a)))
+        assert is_permutation(ind, shape[1])
+        ns = agreed_pivot_prefix(ind[:k], r, oind[:k], orr[:k], dtype)
+        assert (ns == want) if f64 else (ns >= want // 4), f"coop={coop}: {ns} of {want} pivots agree with ?geqp3"
+        assert np.abs(q.T @ q - np.eye(k)).max() <= (1e-12 if f64 else 2e-5)
+        assert rel(q @ r, a[:, ind]) <= (1e-13 if f64 else 1e-5)
+        res[coop] = (q, r, ind)
+    nsb = agreed_pivot_prefix(res[True][2][:k], res[True][1], res[False][2][:k], res[False][1], dtype)
+    assert nsb >= (want if f64 else 1)
+    assert rel(np.abs(np.diag(res[True][1]))[:nsb], np.abs(np.diag(res[False][1]))[:nsb]) <= (1e-10 if f64 else 1e-3)
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_cooperative_panel_gives_way_when_the_candidates_do_not_fit(dtype):
+    """600 columns of identical norm: every column ties at the candidate threshold, more than the cooperative launch has waves;
+    it leaves the panel untouched and the step kernels factor it (positions in order, as ?geqp3 does)."""
+    n = 600
+    e = np.eye(n, dtype=dtype)
+    q, r, ind = (npy(t) for t in rc.pivoted_qr(e))
+    assert np.array_equal(ind, np.arange(n)) and np.abs(np.abs(r) - e).max() <= 1e-6
+    rng = np.random.default_rng(3)
+    u = np.linalg.qr(rng.standard_normal((700, n)))[0].astype(dtype)  # orthonormal columns: all norms 1 up to rounding
+    q, r, ind = (npy(t) for t in rc.pivoted_qr(u))
+    assert is_permutation(ind, n) and rel(q @ r, u[:, ind]) <= (1e-13 if dtype == np.float64 else 1e-5)
+
+
 def test_rccl_self_gather_of_the_packed_factors():
     """rc_comm_* on one GPU (world 1): the packed buffer of a small batch goes through the library's RCCL gather unchanged.
     (The multi-rank layout logic is covered on the CPU: tests/test_dist_cpu.py.)"""
