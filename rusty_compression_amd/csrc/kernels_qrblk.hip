@@ -720,8 +720,9 @@ __device__ inline double qc_ld(const double *p) { return __hip_atomic_load(p, __
 #ifdef RC_QRC_TIMING
 __device__ unsigned long long g_qrc_dbg[8];
 #endif
-template <typename T, int NE>
-__global__ __launch_bounds__(512) void k_qrb_coop(QrbCoopArgs<T> a) {
+// WPE: waves per SIMD the register allocation must leave room for (4 = two workgroups per CU = half the budget units)
+template <typename T, int NE, int WPE>
+__global__ __launch_bounds__(512, WPE) void k_qrb_coop(QrbCoopArgs<T> a) {
     constexpr int VW = 16 / (int)sizeof(T);
     constexpr int NW = 8;
     constexpr int ROWS = 64 * VW * NE;
@@ -755,16 +756,20 @@ __global__ __launch_bounds__(512) void k_qrb_coop(QrbCoopArgs<T> a) {
 
     const int ci = wg * NW + wv;
     const bool have = __builtin_amdgcn_readfirstlane((int)(ci < ncand && !aborted)) != 0;
-    const int c = have ? a.P.cand[ci] : 0;
+    const int c = __builtin_amdgcn_readfirstlane(have ? a.P.cand[ci] : 0);
     T x[NE][VW];
     {
+        // (branch free: the row index is clamped into the matrix and the value masked; per-element predicates are written as
+        // "lane-constant < scalar" so that nothing per element stays alive for the write-back at the end)
         const T *col = a.w.p + (int64_t)c * a.w.cs + j0;
+        const int lq = VW * lane;
 #pragma unroll
         for (int e = 0; e < NE; ++e)
 #pragma unroll
             for (int q = 0; q < VW; ++q) {
-                const int r = VW * lane + 64 * VW * e + q;
-                x[e][q] = (have && r < rows) ? col[r] : (T)0;
+                const int r = lq + 64 * VW * e + q;
+                const T val = col[min(r, rows - 1)];
+                x[e][q] = (have && lq + q < rows - 64 * VW * e) ? val : (T)0;
             }
     }
     int mypos = __builtin_amdgcn_readfirstlane(have ? a.P.cpos[0][ci] : kNoInt);
@@ -961,7 +966,7 @@ __global__ __launch_bounds__(512) void k_qrb_coop(QrbCoopArgs<T> a) {
         if (have) {
             // f32: the reflector stays in registers between the dot product and the update (one LDS pass); f64: two passes of
             // four vectors at a time (register budget)
-            constexpr bool VREG = sizeof(T) == 4;
+            constexpr bool VREG = false;  // (the reflector in registers between the two passes: one LDS pass less, but 64 registers that cost the second workgroup per CU)
             T vr[VREG ? NE : 1][VW];
             T dot = 0;
 #pragma unroll
@@ -1054,14 +1059,17 @@ __global__ __launch_bounds__(512) void k_qrb_coop(QrbCoopArgs<T> a) {
     // ---- the panel is done: columns, norms and the permutation go back -------------------------------------------------------
     if (!aborted) {
         if (have) {
-            T *col = a.w.p + (int64_t)c * a.w.cs + j0;
+            // (the column's addresses are formed afresh from an opaque copy of its index: kept alive from the prologue they
+            // would cost one 64-bit register pair per element across the whole loop)
+            int c2 = c, rows_e = rows;
+            asm volatile("" : "+s"(c2), "+s"(rows_e));
+            T *col = a.w.p + (int64_t)c2 * a.w.cs + j0;
+            const int lq = VW * lane;
 #pragma unroll
             for (int e = 0; e < NE; ++e)
 #pragma unroll
-                for (int q = 0; q < VW; ++q) {
-                    const int r = VW * lane + 64 * VW * e + q;
-                    if (r < rows) col[r] = x[e][q];
-                }
+                for (int q = 0; q < VW; ++q)
+                    if (lq + q < rows_e - 64 * VW * e) col[lq + 64 * VW * e + q] = x[e][q];
             if (lane == 0) {
                 a.vn1[c] = vn1;
                 if (renormed) a.vn2[c] = vn2;
@@ -1139,11 +1147,14 @@ template <typename T>
 static void qrb_coop_launch(rc_context *c, QrbCoopArgs<T> a, int g, int rows) {
     constexpr int NE_BIG = coop_ne_big<T>(), NE_SMALL = NE_BIG / 4;
     const bool small = rows <= 64 * (16 / (int)sizeof(T)) * NE_SMALL;
-    static const unsigned units_big = coop_units_per_wg(k_qrb_coop<T, NE_BIG>), units_small = coop_units_per_wg(k_qrb_coop<T, NE_SMALL>);
+    // f64 with 96 doubles of column per lane needs the whole register file of a SIMD for two waves; everything else leaves room
+    // for a second workgroup on the CU
+    constexpr int WPE_BIG = sizeof(T) == 8 ? 2 : 4;
+    static const unsigned units_big = coop_units_per_wg(k_qrb_coop<T, NE_BIG, WPE_BIG>), units_small = coop_units_per_wg(k_qrb_coop<T, NE_SMALL, 4>);
     a.need = (unsigned)g * (small ? units_small : units_big);
     coop_gate_launch(c, a.need, a.sync, a.hdr, 2 * g * 5);
-    if (small) hipLaunchKernelGGL((k_qrb_coop<T, NE_SMALL>), dim3((unsigned)g), dim3(512), 0, c->stream, a);
-    else hipLaunchKernelGGL((k_qrb_coop<T, NE_BIG>), dim3((unsigned)g), dim3(512), 0, c->stream, a);
+    if (small) hipLaunchKernelGGL((k_qrb_coop<T, NE_SMALL, 4>), dim3((unsigned)g), dim3(512), 0, c->stream, a);
+    else hipLaunchKernelGGL((k_qrb_coop<T, NE_BIG, WPE_BIG>), dim3((unsigned)g), dim3(512), 0, c->stream, a);
 }
 
 // One factorization as a resumable job: issue() enqueues a panel's kernels and the read-back of its state, finish() -- once
