@@ -1097,27 +1097,27 @@ __global__ __launch_bounds__(512, WPE) void k_qrb_coop(QrbCoopArgs<T> a) {
 
 // T factor of a cooperative panel from the recorded v_t^T v_k (?larft, forward / columnwise): T(0:k, k) = -tau_k T(0:k, 0:k) d(0:k, k)
 template <typename T>
-__global__ __launch_bounds__(64) void k_qrb_build_t(const T *D, const T *tau, int j0, int kb, T *Tm) {
+__global__ __launch_bounds__(1024) void k_qrb_build_t(const T *D, const T *tau, int j0, int kb, T *Tm) {
+    // thread (i, t) = (tid / 32, tid % 32): the 32 products of row i with d(:, k), summed over the 32 lanes of a half wave
     __shared__ T Tl[kNB * kNB], Dl[kNB * kNB], taul[kNB];
-    const int i = threadIdx.x;
-    for (int e = i; e < kNB * kNB; e += 64) {
-        Tl[e] = 0;
-        const int t = e % kNB, k = e / kNB;
-        Dl[e] = (t < k && k < kb) ? D[e] : (T)0;
+    static_assert(kNB == 32, "one half wave per row of T");
+    const int tid = threadIdx.x, i = tid >> 5, t = tid & 31;
+    {
+        Tl[tid] = 0;
+        const int tt = tid % kNB, kk = tid / kNB;
+        Dl[tid] = (tt < kk && kk < kb) ? D[tid] : (T)0;
     }
-    if (i < kNB) taul[i] = i < kb ? tau[j0 + i] : (T)0;
+    if (tid < kNB) taul[tid] = tid < kb ? tau[j0 + tid] : (T)0;
     __syncthreads();
     for (int k = 0; k < kb; ++k) {
-        const T tk = taul[k];
-        if (i < k) {
-            T acc = 0;
-            for (int t = i; t < k; ++t) acc = fma(Tl[i + t * kNB], Dl[t + k * kNB], acc);
-            Tl[i + k * kNB] = -tk * acc;
-        }
-        if (i == k) Tl[k + k * kNB] = tk;
+        T p = (t >= i && t < k && i < k) ? Tl[i + t * kNB] * Dl[t + k * kNB] : (T)0;
+        p = group_sum_dpp<16>(p);
+        p += __shfl_xor(p, 16, 64);  // the two rows of 16 lanes of the half wave
+        if (t == 0 && i < k) Tl[i + k * kNB] = -taul[k] * p;  // (column k: nobody reads it in this step)
+        if (tid == 0) Tl[k + k * kNB] = taul[k];
         __syncthreads();
     }
-    for (int e = i; e < kNB * kNB; e += 64) Tm[e] = Tl[e];
+    Tm[tid] = Tl[tid];
 }
 
 static int env_int_b(const char *name, int dflt) {
@@ -1358,7 +1358,7 @@ bool qrb_finish(BlockedQrcpJob<T> *J) {
         Mat<T> ym = rowmajor(J->Y, kb, n, J->ldy);
         gemm<T>(c, 1, vpp.t(), w.sub(j0, rows, 0, n), 0, ym);
     }
-    if (coop) hipLaunchKernelGGL(k_qrb_build_t<T>, dim3(1), dim3(64), 0, c->stream, J->coop.D, J->tau, (int)j0, kb, J->Tm);
+    if (coop) hipLaunchKernelGGL(k_qrb_build_t<T>, dim3(1), dim3(1024), 0, c->stream, J->coop.D, J->tau, (int)j0, kb, J->Tm);
     else hipLaunchKernelGGL(k_qrb_scatter<T>, dim3((unsigned)cdivb(std::max(h.ncand, 1), 256)), dim3(256), 0, c->stream, w, (int)j0, kb, J->P, J->vn1);
     hipLaunchKernelGGL(k_qrb_finish<T>, dim3((unsigned)cdivb(n, 256)), dim3(256), 0, c->stream, w, (int)j0, kb, J->pos, J->is_cand, J->vn1, J->vn2, J->Fm, J->Y, J->ldy,
                        J->Tm, vpp, J->flag, coop ? 1 : 0);
