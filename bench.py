@@ -364,14 +364,23 @@ def main():
                 rec = json.load(open(tpath))
             except Exception:
                 continue
-            traffic_src = {"file": "profiles/" + tname, "source": rec.get("source"), "kernel": rec.get("kernel")}
             cur = sketch_kernel_name()
-            if rec.get("kernel") is None or cur is None or rec.get("kernel") == cur:
-                traffic = rec.get("k_gemm_mfma_sketch_bytes_per_launch")
+            norm = lambda x: x.replace(" ", "") if x else x
+            per_kernel = {norm(kn): v for kn, v in rec.get("kernels", {}).items()}
+            if cur is not None and norm(cur) in per_kernel:
+                # one record per kernel instantiation (tools/gpu_round2_profiles.sh writes them from the PMC passes)
+                ent = per_kernel[norm(cur)]
+                traffic = ent.get("bytes_per_launch")
+                traffic_src = {"file": "profiles/" + tname, "source": rec.get("source"), "kernel": cur, "fetch_bytes": ent.get("fetch_bytes"),
+                               "write_bytes": ent.get("write_bytes"), "launches": ent.get("launches")}
             else:
-                traffic_src["stale"] = "PMC pass was taken on %s, the library now launches %s" % (rec.get("kernel"), cur)
+                traffic_src = {"file": "profiles/" + tname, "source": rec.get("source"), "kernel": rec.get("kernel")}
+                if rec.get("kernel") is None or cur is None or norm(rec.get("kernel")) == norm(cur):
+                    traffic = rec.get("k_gemm_mfma_sketch_bytes_per_launch")
+                else:
+                    traffic_src["stale"] = "PMC pass was taken on %s, the library now launches %s" % (rec.get("kernel"), cur)
             break
-        roof = {"bound": "mfma", "kernel": "k_gemm_f64q (sketch Y = A*Omega, %dx%dx%d, run as Y^T = Omega^T A^T)" % (m, l, n), "achieved": round(achieved, 3),
+        roof = {"bound": "mfma", "kernel": "%s (sketch Y = A*Omega, %dx%dx%d, run as Y^T = Omega^T A^T)" % (sketch_kernel_name() or "k_gemm_f64", m, l, n), "achieved": round(achieved, 3),
                 "peak": F64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / F64_MFMA_PEAK_TFLOPS, 4), "traffic": traffic, "traffic_source": traffic_src,
                 "avg_launch_ms": round(ms_launch, 4), "gemm_ms": round(ms_gemm, 4), "splitk_reduce_ms": round(ms_reduce, 4), "launches_timed": len(samples),
                 "launch_ms_samples_before_timed_region": [round(x[key], 4) for x in prof_before if key in x],

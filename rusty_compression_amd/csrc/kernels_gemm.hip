@@ -535,8 +535,9 @@ static int env_int(const char *name, int dflt) {
     return e ? atoi(e) : dflt;
 }
 
+// target_wgs / min_ksteps (0 = the defaults below): a bandwidth-bound product asks for more, shorter workgroups
 template <typename T, int ALAY, int BLAY, int BM, int BN, int BK, int WM, int WN, int VEC, int NBUF = 2>
-static void launch_cfg(rc_context *c, GemmArgs<T> g) {
+static void launch_cfg(rc_context *c, GemmArgs<T> g, int target_wgs = 0, int min_ksteps = 0) {
     constexpr int NT = WM * WN * 64;
     typedef TileStager<T, ALAY, BM, BK, NT, VEC> StA;
     typedef TileStager<T, BLAY == 1 ? 0 : 1, BN, BK, NT, VEC> StB;
@@ -553,10 +554,11 @@ static void launch_cfg(rc_context *c, GemmArgs<T> g) {
     // amortise its prologue / slab write, and the reduction reads 4x less than with 128 slabs
     static const int target_big = env_int("RC_GEMM_TARGET_WGS", 256), target_small = env_int("RC_GEMM_SMALL_TARGET", 32);
     // with many compressions in flight (RC_OPT_CONCURRENCY_HINT) the other streams fill the chip: wide products stay un-split
-    const int target = tiles >= 8 ? (c->opt_lanes >= 8 && tiles >= 32 ? 1 : target_big) : target_small;
+    const int target = target_wgs > 0 ? target_wgs : tiles >= 8 ? (c->opt_lanes >= 8 && tiles >= 32 ? 1 : target_big) : target_small;
     int splits = 1;
     const int64_t ksteps = cdiv(g.K, BK);
-    while (tiles * splits < target && splits < 128 && ksteps / (splits * 2) >= (tiles >= 32 ? 16 : 4)) splits *= 2;
+    const int min_ks = min_ksteps > 0 ? min_ksteps : (tiles >= 32 ? 16 : 4);
+    while (tiles * splits < target && splits < 128 && ksteps / (splits * 2) >= min_ks) splits *= 2;
     g.kchunk = cdiv(cdiv(g.K, splits), BK) * BK;
     splits = (int)cdiv(g.K, g.kchunk);
     if (splits < 1) splits = 1;
@@ -704,12 +706,23 @@ static void launch_shape(rc_context *c, const GemmArgs<T> &g) {
     // Skinny outputs (the sketch Y = A Omega has N = k + p ~ 69..133; the range
     // projection B = Q^H A has M = k ~ 64..128) get tiles that cover the short
     // side once, so the long operand streams from HBM exactly once.
-    static const int vn = env_int("RC_GEMM_SKINNY_N", 0), vm = env_int("RC_GEMM_SKINNY_M", 0);
+    static const int vn = env_int("RC_GEMM_SKINNY_N", 0), vm = env_int("RC_GEMM_SKINNY_M", 0), m32 = env_int("RC_GEMM_F32_M32", 2);
     if (g.M <= 144 && g.N <= 144 && g.M > 80 && g.N > 80) launch_cfg<T, ALAY, BLAY, 144, 144, 16, 3, 3, VEC>(c, g);
     else if (g.N <= 80) launch_cfg<T, ALAY, BLAY, 128, 80, 16, 4, 1, VEC>(c, g);
     else if (g.N <= 144) {
         if (vn == 1) launch_cfg<T, ALAY, BLAY, 128, 144, 16, 4, 1, VEC>(c, g);
         else launch_cfg<T, ALAY, BLAY, 256, 144, 16, 8, 1, VEC>(c, g);
+    } else if (g.M <= 32 && sizeof(T) == 4 && ALAY == 0 && BLAY == 1 && VEC == 2 && g.K >= 512 && m32) {
+        // Y = V^T A of the blocked QRCP (32 x n x m, both operands K-contiguous, HBM-bound at 32 flops per element of A):
+        // 32-row tiles instead of 80 and many short workgroups (16 K slabs instead of 8) so that enough loads are in flight;
+        // measured on 32 x 4096 x 4096 f32: 76 + 6 us (80-row tiles, 8 slabs) -> 37 + 9 us.  (RC_GEMM_F32_M32=1: 32-deep K tiles,
+        // every row of a tile a whole 128-byte line: 43 + 8 us.)
+        if constexpr (sizeof(T) == 4 && ALAY == 0 && BLAY == 1 && VEC == 2) {
+            // HBM-bound (32 flops per element of A): many short workgroups keep enough loads in flight
+            static const int tw = env_int("RC_GEMM_F32_M32_WGS", 512), mk = env_int("RC_GEMM_F32_M32_MINK", 4);
+            if (m32 == 2) launch_cfg<T, ALAY, BLAY, 32, 128, 16, 1, 4, VEC>(c, g, tw, mk);
+            else launch_cfg<T, ALAY, BLAY, 32, 128, 32, 1, 4, VEC>(c, g, tw, mk);
+        }
     } else if (g.M <= 80) launch_cfg<T, ALAY, BLAY, 80, 128, 16, 1, 4, VEC>(c, g);
     else if (g.M <= 144) {
         if (vm == 1) launch_cfg<T, ALAY, BLAY, 144, 128, 16, 1, 4, VEC>(c, g);

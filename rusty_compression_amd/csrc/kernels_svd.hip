@@ -656,6 +656,92 @@ static void launch_lds_lpp(rc_context *c, Mat<T> g, Mat<T> uc, T *s, Mat<T> vc, 
     else launch_lds<T, LPP, 6 * U>(c, g, uc, s, vc, lds, ld, max_sweeps);  // f32 up to n = 192 (the LDS bound is ~200)
 }
 
+// ?gesdd returns an orthonormal U also for a rank-deficient matrix; the one-sided Jacobi iteration leaves a ZERO left vector for
+// every zero singular value.  This pass completes them (LAPACK's convention up to the choice of the basis of the null space, which
+// no caller can observe through U S V^T): for each zero column, the unit vector with the largest component outside the span of the
+// columns before it, orthogonalised twice against them (classical Gram-Schmidt with one re-orthogonalisation) and normalised.
+// One workgroup; returns at once when the smallest singular value is positive (the values are sorted), which is every call of
+// the hot path.  uc: n x n column-major.
+template <typename T>
+__global__ __launch_bounds__(1024) void k_complete_left_basis(Mat<T> uc, const T *s) {
+    extern __shared__ __attribute__((aligned(16))) char cb_raw[];
+    T *v = reinterpret_cast<T *>(cb_raw);          // n
+    T *d = v + uc.rows;                            // n: projections
+    __shared__ T red_v[16];
+    __shared__ int red_i[16];
+    __shared__ int sh_p;
+    __shared__ T sh_nrm;
+    const int n = (int)uc.rows, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    if (!(s[n - 1] == (T)0)) return;
+    int z = 0;  // number of positive singular values (sorted descending): columns z .. n-1 are the zero ones
+    for (int j = 0; j < n; ++j) z += s[j] > (T)0 ? 1 : 0;
+    for (int j = z; j < n; ++j) {
+        // residual of every unit vector: 1 - sum_c U(p, c)^2 over the columns before j
+        T best = (T)-1;
+        int bp = 0;
+        for (int p = tid; p < n; p += 1024) {
+            T acc = 1;
+            for (int c2 = 0; c2 < j; ++c2) { const T x = uc.p[p + (int64_t)c2 * uc.cs]; acc = fma(-x, x, acc); }
+            if (acc > best) { best = acc; bp = p; }
+        }
+        const T mx = wave_max_dpp(best);
+        const int cand = wave_min_dpp(best == mx ? bp : 0x7fffffff);
+        if (lane == 0) { red_v[wv] = mx; red_i[wv] = cand; }
+        __syncthreads();
+        if (tid == 0) {
+            T b = red_v[0];
+            int bi = red_i[0];
+            for (int w = 1; w < 16; ++w)
+                if (red_v[w] > b || (red_v[w] == b && red_i[w] < bi)) { b = red_v[w]; bi = red_i[w]; }
+            sh_p = bi;
+        }
+        __syncthreads();
+        const int p = sh_p;
+        for (int i = tid; i < n; i += 1024) v[i] = i == p ? (T)1 : (T)0;
+        __syncthreads();
+        for (int pass = 0; pass < 2; ++pass) {
+            for (int c2 = tid; c2 < j; c2 += 1024) {
+                T acc = 0;
+                for (int i = 0; i < n; ++i) acc = fma(uc.p[i + (int64_t)c2 * uc.cs], v[i], acc);
+                d[c2] = acc;
+            }
+            __syncthreads();
+            for (int i = tid; i < n; i += 1024) {
+                T acc = v[i];
+                for (int c2 = 0; c2 < j; ++c2) acc = fma(-uc.p[i + (int64_t)c2 * uc.cs], d[c2], acc);
+                v[i] = acc;
+            }
+            __syncthreads();
+        }
+        T part = 0;
+        for (int i = tid; i < n; i += 1024) part = fma(v[i], v[i], part);
+        part = wave_sum_dpp(part);
+        if (lane == 0) red_v[wv] = part;
+        __syncthreads();
+        if (tid == 0) {
+            T t = 0;
+            for (int w = 0; w < 16; ++w) t += red_v[w];
+            sh_nrm = sqrt(t);
+        }
+        __syncthreads();
+        const T inv = (T)1 / sh_nrm;
+        for (int i = tid; i < n; i += 1024) uc.p[i + (int64_t)j * uc.cs] = v[i] * inv;
+        __threadfence();
+        __syncthreads();
+    }
+}
+
+template <typename T>
+void complete_left_basis(rc_context *c, Mat<T> uc, const T *s) {
+    static const bool on = [] { const char *e = getenv("RC_SVD_COMPLETE_BASIS"); return !e || atoi(e) != 0; }();  // experiments
+    if (!on || uc.rows == 0 || uc.rows != uc.cols || uc.rs != 1) return;
+    const size_t lds = 2 * (size_t)uc.rows * sizeof(T);
+    if (lds > 64 * 1024) return;  // (cores beyond 4096 x 4096 f64 keep the zero vectors)
+    hipLaunchKernelGGL(k_complete_left_basis<T>, dim3(1), dim3(1024), lds, c->stream, uc, s);
+}
+template void complete_left_basis<double>(rc_context *, Mat<double>, const double *);
+template void complete_left_basis<float>(rc_context *, Mat<float>, const float *);
+
 template <typename T>
 void jacobi_svd(rc_context *c, Mat<T> g, Mat<T> vwork, Mat<T> uc, T *s, Mat<T> vc) {
     RC_REQUIRE(g.rows == g.cols && g.rs == 1 && vwork.rs == 1, RC_LAYOUT_ERROR, "jacobi_svd: square column-major core required");

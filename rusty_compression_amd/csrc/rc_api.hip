@@ -337,6 +337,7 @@ void svd_core(rc_context *c, Mat<T> wt, bool transposed, Mat<T> u, T *s, Mat<T> 
     }
     Mat<T> vwork = tmp_colmajor<T>(c, r, r), uc = tmp_colmajor<T>(c, r, r), vc = tmp_colmajor<T>(c, r, r);
     jacobi_svd(c, core, vwork, uc, s, vc);
+    complete_left_basis(c, uc, s);  // (?gesdd: U stays orthonormal when singular values are zero; no-op otherwise)
     if (!transposed) {
         // a = Q_w R = (Q_w Uc) S Vc^T
         gemm<T>(c, 1, qw, uc, 0, u);

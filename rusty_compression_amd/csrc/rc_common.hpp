@@ -206,6 +206,7 @@ template <typename T> void adaptive_residual_update(rc_context *c, Mat<T> y, Mat
 
 // C = alpha * A * B + beta * C on views (transposes are expressed through strides)
 template <typename T> void gemm(rc_context *c, T alpha, Mat<T> a, Mat<T> b, T beta, Mat<T> cmat);
+template <typename T> void complete_left_basis(rc_context *c, Mat<T> uc, const T *s);  // kernels_svd.hip: orthonormal vectors for zero singular values
 
 // Householder QR with optional column pivoting (LAPACK ?geqp3 / ?laqp2 semantics).
 //   w      : m x n COLUMN-MAJOR working matrix (cs = ld, rs = 1), overwritten

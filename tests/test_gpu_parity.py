@@ -288,6 +288,30 @@ def test_svd_cores_beyond_the_lds_limit(dtype, shape):
         assert np.abs(vt[:lead] @ vt[:lead].T - np.eye(lead)).max() <= (1e-11 if f64 else 1e-4)
 
 
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+@pytest.mark.parametrize("shape", [(50, 30), (30, 50), (128, 128), (8, 8)])
+def test_svd_with_exactly_zero_singular_values_keeps_u_orthonormal(dtype, shape):
+    """?gesdd returns an orthonormal U for rank-deficient input (compute_svd.rs:18-27 -> svddc); the Jacobi core completes the
+    left vectors of zero singular values (k_complete_left_basis).  Zero columns / rows make singular values EXACTLY zero."""
+    f64 = dtype == np.float64
+    rng = np.random.default_rng(shape[0] + 3 * shape[1])
+    m, n = shape
+    r = min(m, n)
+    a = rng.standard_normal(shape).astype(dtype)
+    a[:, n // 3:] = 0  # only n // 3 nonzero columns
+    a[m // 2:, :] = 0  # and m // 2 nonzero rows
+    u, s, vt = (npy(t) for t in rc.compute_svd(a))
+    rank = min(n // 3, m // 2)
+    assert np.all(s[rank:] == 0) and np.all(s[:rank] > 0)
+    tol = 1e-12 if f64 else 2e-5
+    assert np.abs(u.T @ u - np.eye(r)).max() <= tol, "left vectors of zero singular values complete the basis"
+    assert np.abs(vt @ vt.T - np.eye(r)).max() <= tol
+    assert rel((u * s) @ vt, a) <= (1e-13 if f64 else 1e-5)
+    z = np.zeros(shape, dtype=dtype)
+    u, s, vt = (npy(t) for t in rc.compute_svd(z))
+    assert np.all(s == 0) and np.abs(u.T @ u - np.eye(r)).max() <= tol and np.abs(vt @ vt.T - np.eye(r)).max() <= tol
+
+
 @pytest.mark.parametrize("shape", [(128, 128), (100, 50), (50, 100), (133, 133), (300, 40)])
 def test_svd_of_clustered_and_repeated_singular_values(shape):
     """Clustered / (near-)equal singular values: a rotation between two such columns has an O(1) angle however small the
