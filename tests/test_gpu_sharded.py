@@ -1,0 +1,91 @@
+"""one matrix sharded by rows over several ranks (rusty_compression_amd/sharded.py).  The GPU box of the
+test tier has ONE GPU, so the ranks are separate processes on that GPU with a gloo group (the module stages its two small
+collectives through the host there; on a multi-GPU node the same code runs them over RCCL).  The assembled result must be the
+single-GPU pipeline's: same singular values, same subspace, same pivots, same ID."""
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from tests.helpers import agreed_pivot_prefix, rel
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _run_ranks(world, tmp_path, env_extra):
+    port = _free_port()
+    procs = []
+    for rank in range(world):
+        env = dict(os.environ, RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), **env_extra)
+        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "sharded_worker.py"), str(tmp_path / f"rank{rank}.npz")], env=env,
+                                      stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
+    outs = [p.communicate(timeout=600)[0].decode() for p in procs]
+    for p, o in zip(procs, outs):
+        assert p.returncode == 0, o[-2000:]
+    return [np.load(tmp_path / f"rank{rank}.npz") for rank in range(world)]
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_row_sharded_rsvd_id_matches_the_single_gpu_pipeline(world, tmp_path):
+    import torch
+
+    import rusty_compression_amd as rc
+    from tests.sharded_worker import test_matrix
+
+    m, n, k, p, seed = 2048, 1024, 64, 5, 9
+    parts = _run_ranks(world, tmp_path, dict(SH_M=str(m), SH_N=str(n), SH_K=str(k), SH_P=str(p), SH_SEED=str(seed)))
+    # replicated outputs are bit-identical on every rank
+    for f in ("s", "vt", "r", "ind", "z"):
+        for q in parts[1:]:
+            assert np.array_equal(parts[0][f], q[f]), f
+    assert np.array_equal(np.concatenate([q["rows"] for q in parts]), np.arange(m))
+    u, rq, qq, c = (np.concatenate([q[f] for q in parts]) for f in ("u", "range_q", "qr_q", "c"))
+    s, vt, r, ind, z = (parts[0][f] for f in ("s", "vt", "r", "ind", "z"))
+
+    a = test_matrix(m, n)
+    an = a.cpu().numpy()
+    # the single-GPU pipeline with the same Omega stream
+    q1 = rc.sample_range_by_rank(a, k, p, rc.Rng(seed))
+    svd1 = rc.SVD.compute_from_range_estimate(q1, a)
+    qr1 = rc.QR.compute_from_range_estimate(q1, a)
+    cid1 = qr1.column_id()
+    q1n, s1, r1, ind1 = q1.cpu().numpy(), svd1.s.cpu().numpy(), qr1.r.cpu().numpy(), qr1.ind.cpu().numpy()
+
+    assert np.abs(rq.T @ rq - np.eye(k)).max() <= 1e-12 and np.abs(u.T @ u - np.eye(k)).max() <= 1e-12 and np.abs(qq.T @ qq - np.eye(k)).max() <= 1e-12
+    assert rel(rq @ rq.T @ an, q1n @ q1n.T @ an) <= 1e-9, "same range (compared through the projected matrix)"
+    assert rel(s, s1) <= 1e-10
+    err, err1 = rel((u * s) @ vt, an), rel((svd1.u.cpu().numpy() * s1) @ svd1.vt.cpu().numpy(), an)
+    assert abs(err - err1) <= 1e-10 and err < 1e-4
+    ns = agreed_pivot_prefix(ind[:k], r, ind1[:k], r1, np.float64)
+    assert ns >= k - 2, f"{ns} of {k} pivots of B agree with the single-GPU factorization"
+    assert sorted(ind.tolist()) == list(range(n))
+    assert rel(qq @ r, an[:, ind] - (an[:, ind] - rq @ (rq.T @ an[:, ind]))) <= 1e-10, "Q R = (range range^T A) P"
+    assert rel(c, an[:, ind[:k]] - (an[:, ind[:k]] - rq @ (rq.T @ an[:, ind[:k]]))) <= 1e-9, "C = the selected columns of the projected matrix"
+    assert abs(rel(c @ z, an) - rel(cid1.c.cpu().numpy() @ cid1.z.cpu().numpy(), an)) <= 1e-8
+
+
+def test_row_sharded_world_one_is_the_plain_pipeline():
+    """No process group: the sharded entry point degenerates to one rank and must agree with the plain calls."""
+    import rusty_compression_amd as rc
+    from rusty_compression_amd import sharded
+    from tests.sharded_worker import test_matrix
+
+    a = test_matrix(1024, 768)
+    res = sharded.rsvd_id_row_sharded(a, 48, 5, 3)
+    q1 = rc.sample_range_by_rank(a, 48, 5, rc.Rng(3))
+    svd1 = rc.SVD.compute_from_range_estimate(q1, a)
+    an = a.cpu().numpy()
+    assert rel(res.s.cpu().numpy(), svd1.s.cpu().numpy()) <= 1e-10
+    rq, q1n = res.range_q.cpu().numpy(), q1.cpu().numpy()
+    assert rel(rq @ (rq.T @ an), q1n @ (q1n.T @ an)) <= 1e-9
+    assert rel(res.c.cpu().numpy() @ res.z.cpu().numpy(), an) < 1e-4
