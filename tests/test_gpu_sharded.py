@@ -81,11 +81,14 @@ def test_row_sharded_world_one_is_the_plain_pipeline():
     from tests.sharded_worker import test_matrix
 
     a = test_matrix(1024, 768)
-    res = sharded.rsvd_id_row_sharded(a, 48, 5, 3)
-    q1 = rc.sample_range_by_rank(a, 48, 5, rc.Rng(3))
+    res = sharded.rsvd_id_row_sharded(a, 64, 5, 3)
+    q1 = rc.sample_range_by_rank(a, 64, 5, rc.Rng(3))
     svd1 = rc.SVD.compute_from_range_estimate(q1, a)
     an = a.cpu().numpy()
     assert rel(res.s.cpu().numpy(), svd1.s.cpu().numpy()) <= 1e-10
     rq, q1n = res.range_q.cpu().numpy(), q1.cpu().numpy()
     assert rel(rq @ (rq.T @ an), q1n @ (q1n.T @ an)) <= 1e-9
-    assert rel(res.c.cpu().numpy() @ res.z.cpu().numpy(), an) < 1e-4
+    qr1 = rc.QR.compute_from_range_estimate(q1, a)
+    cid1 = qr1.column_id()
+    e_sh, e_1 = rel(res.c.cpu().numpy() @ res.z.cpu().numpy(), an), rel(cid1.c.cpu().numpy() @ cid1.z.cpu().numpy(), an)
+    assert abs(e_sh - e_1) <= 1e-8 and e_sh < 1e-2
