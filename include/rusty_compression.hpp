@@ -14,6 +14,7 @@
 #pragma once
 
 #include <cmath>
+#include <complex>
 #include <cstdint>
 #include <stdexcept>
 #include <string>
@@ -71,8 +72,28 @@ class Context {
 };
 
 // ---- scalar dispatch --------------------------------------------------------------------------
+// the reference's `Scalar` (f32, f64, c32, c64; src/lib.rs): Real = the type of norms, tolerances and singular values, wire = how
+// a scalar crosses the C ABI (complex numbers as the (re, im) pairs rc_complex32 / rc_complex64)
+template <typename T> struct Scalar {
+    using real = T;
+    static constexpr bool is_complex = false;
+    static T wire(T v) { return v; }
+};
+template <> struct Scalar<std::complex<float>> {
+    using real = float;
+    static constexpr bool is_complex = true;
+    static rc_complex32 wire(std::complex<float> v) { return rc_complex32{v.real(), v.imag()}; }
+};
+template <> struct Scalar<std::complex<double>> {
+    using real = double;
+    static constexpr bool is_complex = true;
+    static rc_complex64 wire(std::complex<double> v) { return rc_complex64{v.real(), v.imag()}; }
+};
+using c32 = std::complex<float>;
+using c64 = std::complex<double>;
+
 template <typename T> struct Api;
-#define RC_API(T, SUF)                                                                                              \
+#define RC_API(T, SUF, RSUF)                                                                                            \
     template <> struct Api<T> {                                                                                     \
         static constexpr auto random_gaussian = rc_random_gaussian_##SUF;                                           \
         static constexpr auto matmat = rc_matmat_##SUF;                                                             \
@@ -89,7 +110,7 @@ template <typename T> struct Api;
         static constexpr auto qr_column_id = rc_qr_column_id_##SUF;                                                 \
         static constexpr auto lq_row_id = rc_lq_row_id_##SUF;                                                       \
         static constexpr auto qr_from_range_estimate = rc_qr_from_range_estimate_##SUF;                             \
-        static constexpr auto svd_rank_by_tolerance = rc_svd_rank_by_tolerance_##SUF;                               \
+        static constexpr auto svd_rank_by_tolerance = rc_svd_rank_by_tolerance_##RSUF; /* singular values are real */                           \
         static constexpr auto svd_to_mat = rc_svd_to_mat_##SUF;                                                     \
         static constexpr auto svd_to_qr = rc_svd_to_qr_##SUF;                                                       \
         static constexpr auto svd_from_range_estimate = rc_svd_from_range_estimate_##SUF;                           \
@@ -101,8 +122,10 @@ template <typename T> struct Api;
         static constexpr auto sample_range_adaptive = rc_sample_range_adaptive_##SUF;                               \
         static constexpr auto column_id_rank = rc_column_id_rank_##SUF;                                             \
     };
-RC_API(double, f64)
-RC_API(float, f32)
+RC_API(double, f64, f64)
+RC_API(float, f32, f32)
+RC_API(c64, c64, f64)
+RC_API(c32, c32, f32)
 #undef RC_API
 
 // ---- device-resident C-order arrays (the reference's Array2 / Array1<usize>) ----------------------
@@ -190,7 +213,14 @@ inline DeviceMatrix<T> clone_matrix(const DeviceMatrix<T> &src) { return src.lea
 template <typename T>
 DeviceMatrix<T> dot(const DeviceMatrix<T> &a, const DeviceMatrix<T> &b) {  // ndarray .dot
     DeviceMatrix<T> c(a.ctx(), a.nrows(), b.ncols());
-    a.ctx().check(Api<T>::gemm(a.ctx().raw(), 0, 0, (T)1, a.view(), b.view(), (T)0, c.view()));
+    a.ctx().check(Api<T>::gemm(a.ctx().raw(), 0, 0, Scalar<T>::wire((T)1), a.view(), b.view(), Scalar<T>::wire((T)0), c.view()));
+    return c;
+}
+// op(a) op(b) with op = 0: as is, 1: transpose, 2: conjugate transpose (the reference writes `.t().map(|x| x.conj())`)
+template <typename T>
+DeviceMatrix<T> dot_op(int op_a, const DeviceMatrix<T> &a, int op_b, const DeviceMatrix<T> &b) {
+    DeviceMatrix<T> c(a.ctx(), op_a ? a.ncols() : a.nrows(), op_b ? b.nrows() : b.ncols());
+    a.ctx().check(Api<T>::gemm(a.ctx().raw(), op_a, op_b, Scalar<T>::wire((T)1), a.view(), b.view(), Scalar<T>::wire((T)0), c.view()));
     return c;
 }
 template <typename T>
@@ -206,8 +236,8 @@ DeviceMatrix<T> conj_matmat(const DeviceMatrix<T> &op, const DeviceMatrix<T> &x)
     return y;
 }
 template <typename T>
-T rel_diff_fro(const DeviceMatrix<T> &first, const DeviceMatrix<T> &second) {  // RelDiff, src/types.rs:182-188
-    T out = 0;
+typename Scalar<T>::real rel_diff_fro(const DeviceMatrix<T> &first, const DeviceMatrix<T> &second) {  // RelDiff, src/types.rs:182-188
+    typename Scalar<T>::real out = 0;
     first.ctx().check(Api<T>::rel_diff_fro(first.ctx().raw(), first.view(), second.view(), &out));
     return out;
 }
@@ -349,19 +379,20 @@ RowID<T> LQ<T>::row_id() const {
 // ---- svd.rs --------------------------------------------------------------------------------------
 template <typename T>
 struct SVD {  // src/svd.rs:13-20
+    using Real = typename Scalar<T>::real;
     DeviceMatrix<T> u;
-    DeviceBuffer<T> s;
+    DeviceBuffer<Real> s;  // singular values are real for every scalar type
     DeviceMatrix<T> vt;
     int64_t rank() const { return u.ncols(); }
     static SVD compute_from(const DeviceMatrix<T> &a) {  // src/svd.rs:165-169 -> src/compute_svd.rs:18-27
         const int64_t m = a.nrows(), n = a.ncols(), r = m < n ? m : n;
-        SVD out{DeviceMatrix<T>(a.ctx(), m, r), DeviceBuffer<T>(a.ctx(), (std::size_t)r), DeviceMatrix<T>(a.ctx(), r, n)};
+        SVD out{DeviceMatrix<T>(a.ctx(), m, r), DeviceBuffer<Real>(a.ctx(), (std::size_t)r), DeviceMatrix<T>(a.ctx(), r, n)};
         a.ctx().check(Api<T>::compute_svd(a.ctx().raw(), a.view(), out.u.view(), out.s.data(), out.vt.view()));
         return out;
     }
     static SVD compute_from_range_estimate(const DeviceMatrix<T> &range, const DeviceMatrix<T> &op) {  // src/svd.rs:171-183
         const int64_t m = op.nrows(), n = op.ncols(), r = range.ncols() < n ? range.ncols() : n;
-        SVD out{DeviceMatrix<T>(op.ctx(), m, r), DeviceBuffer<T>(op.ctx(), (std::size_t)r), DeviceMatrix<T>(op.ctx(), r, n)};
+        SVD out{DeviceMatrix<T>(op.ctx(), m, r), DeviceBuffer<Real>(op.ctx(), (std::size_t)r), DeviceMatrix<T>(op.ctx(), r, n)};
         op.ctx().check(Api<T>::svd_from_range_estimate(op.ctx().raw(), range.view(), op.view(), out.u.view(), out.s.data(), out.vt.view()));
         return out;
     }
@@ -379,7 +410,7 @@ struct SVD {  // src/svd.rs:13-20
     SVD compress_svd_rank(int64_t max_rank) const {  // src/svd.rs:68-84
         if (max_rank > (int64_t)s.size()) max_rank = (int64_t)s.size();
         auto hs = s.to_host();
-        DeviceBuffer<T> s2(u.ctx(), (std::size_t)max_rank);
+        DeviceBuffer<Real> s2(u.ctx(), (std::size_t)max_rank);
         s2.from_host(hs.data());
         return SVD{u.leading(u.nrows(), max_rank), std::move(s2), vt.leading(max_rank, vt.ncols())};
     }
@@ -406,22 +437,30 @@ DeviceMatrix<T> transpose(const DeviceMatrix<T> &a) {  // owned C-order copy of 
     return out;
 }
 template <typename T>
+DeviceMatrix<T> conj_transpose(const DeviceMatrix<T> &a) {  // owned C-order copy of a^H (= a^T for real scalars)
+    if (!Scalar<T>::is_complex) return transpose(a);
+    std::vector<T> eye((std::size_t)(a.nrows() * a.nrows()), (T)0);
+    for (int64_t i = 0; i < a.nrows(); ++i) eye[(std::size_t)(i * a.nrows() + i)] = (T)1;
+    return dot_op(2, a, 0, DeviceMatrix<T>::from_host(a.ctx(), eye.data(), a.nrows(), a.nrows()));
+}
+template <typename T>
 DeviceMatrix<T> random_orthogonal_matrix(const Context &ctx, int64_t rows, int64_t cols, uint64_t seed, uint64_t offset = 0) {  // src/random_matrix.rs:35-56
     const bool swap = cols > rows;
     auto g = random_gaussian<T>(ctx, swap ? cols : rows, swap ? rows : cols, seed, offset);
     auto u = std::move(SVD<T>::compute_from(g).u);
-    return swap ? transpose(u) : std::move(u);
+    return swap ? conj_transpose(u) : std::move(u);  // src/random_matrix.rs:51-53
 }
 template <typename T>
 DeviceMatrix<T> random_approximate_low_rank_matrix(const Context &ctx, int64_t rows, int64_t cols, double sigma_max, double sigma_min,
                                                    uint64_t seed) {  // src/random_matrix.rs:70-93
     if (!(sigma_min < sigma_max)) throw AssertionFailed("`sigma_min` must be smaller than `sigma_max`");
     if (!(sigma_min > 0.0)) throw AssertionFailed("`sigma_min` must be positive.");
+    using Real = typename Scalar<T>::real;
     const int64_t r = rows < cols ? rows : cols;
-    std::vector<T> hs((std::size_t)r);
+    std::vector<Real> hs((std::size_t)r);
     const double l0 = std::log10(sigma_min), l1 = std::log10(sigma_max);
-    for (int64_t i = 0; i < r; ++i) hs[(std::size_t)i] = (T)std::pow(10.0, r > 1 ? l0 + (l1 - l0) * (double)i / (double)(r - 1) : l0);
-    SVD<T> f{random_orthogonal_matrix<T>(ctx, rows, r, seed, 0), DeviceBuffer<T>(ctx, (std::size_t)r),
+    for (int64_t i = 0; i < r; ++i) hs[(std::size_t)i] = (Real)std::pow(10.0, r > 1 ? l0 + (l1 - l0) * (double)i / (double)(r - 1) : l0);
+    SVD<T> f{random_orthogonal_matrix<T>(ctx, rows, r, seed, 0), DeviceBuffer<Real>(ctx, (std::size_t)r),
              random_orthogonal_matrix<T>(ctx, r, cols, seed, (uint64_t)(rows * r))};
     f.s.from_host(hs.data());
     return f.to_mat();
@@ -454,8 +493,8 @@ ColumnID<T> column_id_rank(const DeviceMatrix<T> &a, int64_t k) {
     return out;
 }
 template <typename T>
-T max_col_norm(const DeviceMatrix<T> &y) {  // :184-191
-    T out = 0;
+typename Scalar<T>::real max_col_norm(const DeviceMatrix<T> &y) {  // :184-191
+    typename Scalar<T>::real out = 0;
     y.ctx().check(Api<T>::max_col_norm(y.ctx().raw(), y.view(), &out));
     return out;
 }

@@ -471,11 +471,16 @@ __global__ __launch_bounds__(256) void k_c_jacobi_round(CV<R> g, CV<R> v, int r,
     const R habs = hypot(apq.re, apq.im);
     const R tol = sqrt((R)M) * NumC<R>::eps();
     if (habs == (R)0 || habs <= tol * sqrt(app) * sqrt(aqq)) return;
-    // q~ = e^{-i phi} q makes p^H q~ = |apq| real: a real Jacobi rotation between p and q~
-    const cplx<R> ph{apq.re / habs, -apq.im / habs};
-    const R zeta = (aqq - app) / ((R)2 * habs);
-    const R t = copysign((R)1, zeta) / (fabs(zeta) + sqrt((R)1 + zeta * zeta));
-    const R cs = (R)1 / sqrt((R)1 + t * t), sn = cs * t;
+    // q~ = e^{-i phi} q makes p^H q~ = |apq| real: a real Jacobi rotation between p and q~.
+    // The phase and the rotation parameters are evaluated in f64 for both precisions (as in the real kernels): in f32,
+    // c^2 + s^2 - 1 and |phase|^2 - 1 have a systematic sign and the thousands of rotations a column undergoes inflate the
+    // singular values by a few 1e-5 (the reference's c32 tests ask for 1e-5: src/svd.rs:291).
+    const double hd = hypot((double)apq.re, (double)apq.im);
+    const cplx<R> ph{(R)((double)apq.re / hd), (R)(-(double)apq.im / hd)};
+    const double zeta = ((double)aqq - (double)app) / (2.0 * hd);
+    const double td = copysign(1.0, zeta) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
+    const double cd = 1.0 / sqrt(1.0 + td * td);
+    const R cs = (R)cd, sn = (R)(cd * td);
     for (int64_t i = lane; i < M; i += 64) {
         const cplx<R> a = gp[i], b = ph * gq[i];
         gp[i] = cs * a - sn * b;

@@ -1,8 +1,8 @@
 // The reference crate's unit tests (rusty-compression v0.1.1) written against the C++ mirror include/rusty_compression.hpp:
 //   src/pivoted_qr.rs:193-317, src/qr.rs:418-616, src/svd.rs:193-321, src/col_interp_decomp.rs:163-242,
 //   src/row_interp_decomp.rs:163-236, src/permutation.rs:187-240.
-// Same test names, same matrices (the reference's generator recipe, seeded), same assertions and tolerances, for every
-// scalar type the mirror is instantiated for.  This is the COMPILED twin of bindings/rust/tests/reference_tests.rs (the
+// Same test names, same matrices (the reference's generator recipe, seeded), same assertions and tolerances, for all four
+// scalar types of the reference (f32, f64, c32, c64): 11 tests x 4 types x 2 shapes + the 2 permutation tests = 90.  This is the COMPILED twin of bindings/rust/tests/reference_tests.rs (the
 // Rust crate cannot be built in this repository's container): tests/test_gpu_parity.py builds it and runs it on the GPU box,
 // the CPU suite compiles and links it.  Prints one line per test and exits non-zero if any assertion failed.
 #include <cmath>
@@ -39,6 +39,13 @@ static void run_test(const std::string &name, F &&body) {
 template <typename T> struct Name;
 template <> struct Name<float> { static const char *get() { return "f32"; } };
 template <> struct Name<double> { static const char *get() { return "f64"; } };
+template <> struct Name<c32> { static const char *get() { return "c32"; } };
+template <> struct Name<c64> { static const char *get() { return "c64"; } };
+// |x| as a double for real and complex entries
+static double mag(float x) { return std::fabs((double)x); }
+static double mag(double x) { return std::fabs(x); }
+static double mag(c32 x) { return (double)std::abs(x); }
+static double mag(c64 x) { return std::abs(x); }
 
 static uint64_t seed_of(const std::string &s) {
     uint64_t h = 0xcbf29ce484222325ull;
@@ -61,8 +68,8 @@ template <typename T>
 static double rel_diff_col(const Host<T> &a, int64_t ca, const Host<T> &b, int64_t cb) {  // RelDiff::rel_diff_l2 on columns
     double d2 = 0, n2 = 0;
     for (int64_t i = 0; i < a.rows; ++i) {
-        const double x = (double)a.at(i, ca), y = (double)b.at(i, cb);
-        d2 += (x - y) * (x - y);
+        const double d = mag((T)(a.at(i, ca) - b.at(i, cb))), y = mag(b.at(i, cb));
+        d2 += d * d;
         n2 += y * y;
     }
     return std::sqrt(d2) / std::sqrt(n2);
@@ -71,8 +78,8 @@ template <typename T>
 static double rel_diff_row(const Host<T> &a, int64_t ra, const Host<T> &b, int64_t rb) {
     double d2 = 0, n2 = 0;
     for (int64_t j = 0; j < a.cols; ++j) {
-        const double x = (double)a.at(ra, j), y = (double)b.at(rb, j);
-        d2 += (x - y) * (x - y);
+        const double d = mag((T)(a.at(ra, j) - b.at(rb, j))), y = mag(b.at(rb, j));
+        d2 += d * d;
         n2 += y * y;
     }
     return std::sqrt(d2) / std::sqrt(n2);
@@ -81,16 +88,16 @@ static double rel_diff_row(const Host<T> &a, int64_t ra, const Host<T> &b, int64
 template <typename T>
 static void group(const Context &ctx, int64_t m, int64_t n, const char *shape) {
     const std::string suf = std::string(Name<T>::get()) + "_" + shape;
-    const bool f32 = sizeof(T) == 4;
+    const bool f32 = sizeof(typename Scalar<T>::real) == 4;
     auto mat_for = [&](const std::string &test, double smin) { return random_approximate_low_rank_matrix<T>(ctx, m, n, 1.0, smin, seed_of(test)); };
 
     // ---- src/pivoted_qr.rs:198-246
     run_test("pivoted_qr_test_" + std::string(shape) + "_" + Name<T>::get(), [&] {
         auto mat = mat_for("pivoted_qr_test_" + suf, 1E-5);
         auto qr = QR<T>::compute_from(mat);
-        auto qtq = host(dot(transpose(qr.q), qr.q));
+        auto qtq = host(dot_op(2, qr.q, 0, qr.q));  // Q^H Q
         for (int64_t i = 0; i < qtq.rows; ++i)
-            for (int64_t j = 0; j < qtq.cols; ++j) CHECK(std::fabs((double)qtq.at(i, j) - (i == j ? 1.0 : 0.0)) < 1E-6);
+            for (int64_t j = 0; j < qtq.cols; ++j) CHECK(mag((T)(qtq.at(i, j) - (T)(i == j ? 1.0 : 0.0))) < 1E-6);
         auto prod = host(dot(qr.q, qr.r)), hm = host(mat);
         auto ind = host_index(qr.ind);
         for (int64_t c = 0; c < prod.cols; ++c) CHECK(rel_diff_col(prod, c, hm, ind[(size_t)c]) < 1E-6);
@@ -99,9 +106,9 @@ static void group(const Context &ctx, int64_t m, int64_t n, const char *shape) {
     run_test("pivoted_lq_test_" + std::string(shape) + "_" + Name<T>::get(), [&] {
         auto mat = mat_for("pivoted_lq_test_" + suf, 1E-5);
         auto lq = LQ<T>::compute_from(mat);
-        auto qqt = host(dot(lq.q, transpose(lq.q)));
+        auto qqt = host(dot_op(0, lq.q, 2, lq.q));  // Q Q^H
         for (int64_t i = 0; i < qqt.rows; ++i)
-            for (int64_t j = 0; j < qqt.cols; ++j) CHECK(std::fabs((double)qqt.at(i, j) - (i == j ? 1.0 : 0.0)) < 1E-6);
+            for (int64_t j = 0; j < qqt.cols; ++j) CHECK(mag((T)(qqt.at(i, j) - (T)(i == j ? 1.0 : 0.0))) < 1E-6);
         auto prod = host(dot(lq.l, lq.q)), hm = host(mat);
         auto ind = host_index(lq.ind);
         for (int64_t r = 0; r < prod.rows; ++r) CHECK(rel_diff_row(prod, r, hm, ind[(size_t)r]) < 1E-6);
@@ -179,8 +186,8 @@ static void group(const Context &ctx, int64_t m, int64_t n, const char *shape) {
         auto ri = host_index(ts.row_ind), ci = host_index(ts.col_ind);
         for (int64_t i = 0; i < rank; ++i)
             for (int64_t j = 0; j < rank; ++j) {
-                const double ref = (double)hm.at(ri[(size_t)i], ci[(size_t)j]);  // mat.apply_permutation(row_ind, ROW).apply_permutation(col_ind, COL)[i, j]
-                CHECK(std::fabs((double)hx.at(i, j) - ref) < 10.0 * tol * std::fabs(ref));
+                const T ref = hm.at(ri[(size_t)i], ci[(size_t)j]);  // mat.apply_permutation(row_ind, ROW).apply_permutation(col_ind, COL)[i, j]
+                CHECK(mag((T)(hx.at(i, j) - ref)) < 10.0 * tol * mag(ref));
             }
     };
     run_test("test_two_sided_from_col_id_compression_by_tol_" + suf, [&] {
@@ -237,6 +244,10 @@ int main() {
     group<float>(ctx, 100, 50, "thin");
     group<double>(ctx, 50, 100, "thick");
     group<float>(ctx, 50, 100, "thick");
+    group<c64>(ctx, 100, 50, "thin");
+    group<c32>(ctx, 100, 50, "thin");
+    group<c64>(ctx, 50, 100, "thick");
+    group<c32>(ctx, 50, 100, "thick");
     permutation_tests(ctx);
     std::printf("%d tests, %d failed\n", tests_run, failures);
     return failures ? 1 : 0;

@@ -1259,7 +1259,7 @@ def test_cpp_mirror_runs_the_reference_examples(tmp_path):
 def test_cpp_twin_of_the_rust_crate_passes_the_reference_unit_tests(tmp_path):
     """tests/cpp/reference_tests.cpp: the reference's own unit tests (src/pivoted_qr.rs:193-317, src/qr.rs:418-616,
     src/svd.rs:193-321, src/col_interp_decomp.rs:163-242, src/row_interp_decomp.rs:163-236, src/permutation.rs:187-240) for
-    f32 / f64, thin / thick, against the C++ mirror -- the compiled twin of bindings/rust/tests/reference_tests.rs."""
+    f32 / f64 / c32 / c64, thin / thick, against the C++ mirror -- the compiled twin of bindings/rust/tests/reference_tests.rs."""
     import subprocess
 
     from tests.test_abi_cpu import build_cpp_mirror_examples
@@ -1268,7 +1268,7 @@ def test_cpp_twin_of_the_rust_crate_passes_the_reference_unit_tests(tmp_path):
     res = subprocess.run([exe], capture_output=True, text=True, timeout=600)
     print(res.stdout[-4000:])
     assert res.returncode == 0, res.stdout[-6000:] + res.stderr
-    assert "46 tests, 0 failed" in res.stdout
+    assert "90 tests, 0 failed" in res.stdout
 
 
 _JACOBI_VARIANT_SNIPPET = r"""
