@@ -333,8 +333,10 @@ def main():
         fn.restype = ctypes.c_char_p
         fn.argtypes = [ctypes.c_void_p]
         with torch.cuda.stream(lanes[0]["stream"]):
-            om = torch.empty((n, l), dtype=dt, device="cuda")
-            y = torch.empty((m, l), dtype=dt, device="cuda")
+            # the same operand layout as inside the library (even leading dimensions: 16-byte vector staging), otherwise the
+            # scalar-staging instantiation would answer
+            om = torch.empty((n, l + (l & 1)), dtype=dt, device="cuda")[:, :l]
+            y = torch.empty((m, l + (l & 1)), dtype=dt, device="cuda")[:, :l]
             lanes[0]["ctx"].call("rc_matmat_f64", _lib.mat(lanes[0]["a"]), _lib.mat(om), _lib.mat(y))
         lanes[0]["ctx"].synchronize()
         nm = fn(lanes[0]["ctx"]._h)
