@@ -24,10 +24,61 @@ from typing import Optional
 
 import torch
 
-from .qr import QR, pivoted_qr
-from .random_matrix import Rng, random_gaussian
-from .svd import compute_svd
-from .types import as_device, conj_matmat, dot, matmat
+
+
+class DeviceOps:
+    """The compute steps of the sharded pipeline on the GPU of this rank, through the C ABI (the default).  tests/test_dist_cpu.py
+    injects the CPU oracle here to exercise the collective plumbing and the TSQR algebra without a GPU -- the same arrangement as
+    `batch.batch_column_id(compute=...)`; the product path never does."""
+
+    @staticmethod
+    def prepare(a_local):
+        from .types import as_device
+
+        return as_device(a_local)
+
+    @staticmethod
+    def random_gaussian(shape, seed, like):
+        from .random_matrix import Rng, random_gaussian
+
+        return random_gaussian(shape, Rng(seed), like.dtype)
+
+    @staticmethod
+    def matmat(a, x):
+        from .types import matmat
+
+        return matmat(a, x)
+
+    @staticmethod
+    def conj_matmat(a, x):
+        from .types import conj_matmat
+
+        return conj_matmat(a, x)
+
+    @staticmethod
+    def dot(a, b):
+        from .types import dot
+
+        return dot(a, b)
+
+    @staticmethod
+    def pivoted_qr(a):
+        from .qr import pivoted_qr
+
+        return pivoted_qr(a)
+
+    @staticmethod
+    def compute_svd(a):
+        from .svd import compute_svd
+
+        return compute_svd(a)
+
+    @staticmethod
+    def column_id(q, r, ind):
+        from .qr import QR
+
+        cid = QR(q, r, ind).column_id()
+        return cid.c, cid.z
 
 
 @dataclass
@@ -80,38 +131,37 @@ def all_reduce_sum(x: torch.Tensor, group=None) -> torch.Tensor:
     return buf.to(x.device)
 
 
-def sample_range_by_rank_sharded(a_local, k: int, p: int, seed: int, group=None) -> torch.Tensor:
+def sample_range_by_rank_sharded(a_local, k: int, p: int, seed: int, group=None, ops=DeviceOps) -> torch.Tensor:
     """Rows of the range basis `sample_range_by_rank` (src/random_sampling.rs:103-118) returns for the stacked matrix."""
-    a = as_device(a_local)
+    a = ops.prepare(a_local)
     m_r, n = a.shape
     l = k + p
     assert m_r >= l, f"every rank needs at least k + p = {l} rows, this one has {m_r}"
     world, rank, _ = _world(group)
-    omega = random_gaussian((n, l), Rng(seed), a.dtype)  # the same stream on every rank
-    y = matmat(a, omega)                                 # m_r x l
-    q_r, r_r, ind_r = pivoted_qr(y)                      # Y_r[:, ind_r] = Q_r R_r
+    omega = ops.random_gaussian((n, l), seed, a)         # the same stream on every rank
+    y = ops.matmat(a, omega)                             # m_r x l
+    q_r, r_r, ind_r = ops.pivoted_qr(y)                  # Y_r[:, ind_r] = Q_r R_r
     inv = torch.empty_like(ind_r)
     inv[ind_r] = torch.arange(l, device=ind_r.device, dtype=ind_r.dtype)
     s_r = r_r[:, inv].contiguous()                       # Y_r = Q_r S_r
     s_all = all_gather_rows(s_r, group)                  # (W l) x l
-    q_s, _, _ = pivoted_qr(s_all)                        # (W l) x l, identical on every rank
+    q_s, _, _ = ops.pivoted_qr(s_all)                    # (W l) x l, identical on every rank
     block = q_s[rank * l:(rank + 1) * l, :min(k, l)].contiguous()
-    return dot(q_r, block)                               # m_r x k
+    return ops.dot(q_r, block)                           # m_r x k
 
 
-def rsvd_id_row_sharded(a_local, k: int, p: int, seed: int, group=None, with_id: bool = True) -> ShardedRsvdId:
+def rsvd_id_row_sharded(a_local, k: int, p: int, seed: int, group=None, with_id: bool = True, ops=DeviceOps) -> ShardedRsvdId:
     """Randomized SVD + pivoted QR + column ID of the row-sharded matrix (the cfg3 pipeline, one matrix over several GPUs)."""
-    a = as_device(a_local)
-    rq = sample_range_by_rank_sharded(a, k, p, seed, group)
+    a = ops.prepare(a_local)
+    rq = sample_range_by_rank_sharded(a, k, p, seed, group, ops)
     kk = rq.shape[1]
-    b_t = conj_matmat(a, rq)                             # n x k: this rank's share of B^H
+    b_t = ops.conj_matmat(a, rq)                         # n x k: this rank's share of B^H
     b = all_reduce_sum(b_t, group).t().contiguous()      # k x n, the same bits everywhere
-    ub, s, vt = compute_svd(b)
-    u = dot(rq, ub)
-    qb, r, ind = pivoted_qr(b)
-    qr_q = dot(rq, qb)
+    ub, s, vt = ops.compute_svd(b)
+    u = ops.dot(rq, ub)
+    qb, r, ind = ops.pivoted_qr(b)
+    qr_q = ops.dot(rq, qb)
     c = z = None
     if with_id:
-        cid = QR(qr_q, r, ind).column_id()
-        c, z = cid.c, cid.z
+        c, z = ops.column_id(qr_q, r, ind)
     return ShardedRsvdId(rq, u, s[:kk], vt, qr_q, r, ind, c, z)
