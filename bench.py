@@ -60,7 +60,26 @@ def work_model(m, n, k, p, with_id=True):
     return fl, by
 
 
+# The contract is ONE JSON line on stdout.  Libraries below us write there too (RCCL prints a version banner at communicator
+# creation), so the process's fd 1 is pointed at stderr for the whole run and the line goes to the original stdout.
+_REAL_STDOUT = None
+
+
+def _guard_stdout():
+    global _REAL_STDOUT
+    if _REAL_STDOUT is None:
+        sys.stdout.flush()
+        _REAL_STDOUT = os.dup(1)
+        os.dup2(2, 1)
+
+
+def _emit(text):
+    sys.stdout.flush()
+    os.write(_REAL_STDOUT if _REAL_STDOUT is not None else 1, (text + "\n").encode())
+
+
 def main():
+    _guard_stdout()
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=12, help="timed rounds; one round = one compression on each lane")
@@ -99,7 +118,9 @@ def main():
         local_rank = 0
     torch.cuda.set_device(local_rank)
     dist = None
-    if world > 1:
+    # RC_BENCH_FORCE_DIST=1 (never set by the driver): take the N > 1 code path -- RCCL init, barriers, MAX all-reduce on a device
+    # tensor -- with a single rank, which is all the RCCL a one-GPU box can run
+    if world > 1 or os.environ.get("RC_BENCH_FORCE_DIST", "0") == "1":
         import torch.distributed as dist  # noqa: F811
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -453,7 +474,7 @@ def main():
             "value_including_h2d": h2d,
             "stage_ms_single_stream_eager": stage_ms,
         }
-        print(json.dumps(line), flush=True)
+        _emit(json.dumps(line))
 
     for ln in lanes:
         if ln["graph"]:
