@@ -156,8 +156,6 @@ __global__ __launch_bounds__(WM *WN * 64) void k_gemm_f64p(GemmArgs<double> g) {
         double *nxt = smem + ((it & 1) ^ 1) * STAGE;
 #pragma unroll
         for (int ks = 0; ks < NKS; ++ks) {
-            constexpr int dummy = 0;
-            (void)dummy;
             if (ks == NKS - 2 && !(DBG & 1)) {
                 // tile it + 1 (in the staging registers since the previous barrier) -> the other buffer; every wave finished
                 // reading that buffer before the previous barrier
@@ -250,8 +248,6 @@ struct DirectRows {
 #pragma unroll
         for (int i = 0; i < PER_WAVE; ++i) {
             const int kk = wave_u * (PER_WAVE / PIECES_ROW) + i / PIECES_ROW;  // uniform
-            constexpr int dummy = 0;
-            (void)dummy;
             const int h = i % PIECES_ROW;                                       // compile time
             const uint32_t soff = __builtin_amdgcn_readfirstlane(tile_off + kk * sk8);
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_ptr_t)(stage + kk * P + h * 128), 16, voff[h], soff, 0, 0);
