@@ -1030,11 +1030,13 @@ def _with_coop_panel(on, fn):
 
 
 @pytest.mark.parametrize("dtype", [np.float64, np.float32])
-@pytest.mark.parametrize("shape", [(157, 520), (301, 700), (300, 400), (1021, 1300), (333, 2000)])
+@pytest.mark.parametrize("shape", [(157, 520), (301, 700), (300, 400), (1021, 1300), (333, 2000), (4400, 640), (3200, 600)])
 def test_cooperative_panels_match_the_step_kernels_and_lapack(dtype, shape):
     """The cooperative register-resident panel (k_qrb_coop) against the step kernels (RC_OPT_COOP_PANEL = 0) and ?geqp3: odd
     row counts (the last 16-byte vector of a column is partly beyond the matrix), more columns than one launch has waves
-    (non-candidates take the Y = V^T A / T-factor route), fewer (every column a candidate), panels ended by the tau test."""
+    (non-candidates take the Y = V^T A / T-factor route), fewer (every column a candidate), panels ended by the tau test, and
+    tall matrices whose first panels have more rows than a wave's registers hold (4096 in f32, 3072 in f64): those run on the
+    step kernels and the factorization switches to cooperative panels once the active rows fit."""
     f64 = dtype == np.float64
     rng = np.random.default_rng(shape[0] * 7 + shape[1])
     a = o.random_approximate_low_rank_matrix(shape, 1.0, 1e-6 if f64 else 1e-3, rng, dtype)
