@@ -1201,7 +1201,7 @@ static unsigned coop_units_per_wg(K kern) {
 }
 
 template <typename T>
-static void qrb_coop_launch(rc_context *c, QrbCoopArgs<T> a, int g, int rows) {
+static bool qrb_coop_launch(rc_context *c, QrbCoopArgs<T> a, int g, int rows) {
     constexpr int NE_BIG = coop_ne_big<T>(), NE_SMALL = NE_BIG / 4;
     const bool small = rows <= 64 * (16 / (int)sizeof(T)) * NE_SMALL;
     // f64 with 96 doubles of column per lane needs the whole register file of a SIMD for two waves; everything else leaves room
@@ -1209,9 +1209,11 @@ static void qrb_coop_launch(rc_context *c, QrbCoopArgs<T> a, int g, int rows) {
     constexpr int WPE_BIG = sizeof(T) == 8 ? 2 : 4;
     static const unsigned units_big = coop_units_per_wg(k_qrb_coop<T, NE_BIG, WPE_BIG>), units_small = coop_units_per_wg(k_qrb_coop<T, NE_SMALL, 4>);
     a.need = (unsigned)g * (small ? units_small : units_big);
+    if (a.need > coop_budget_units(c->device)) return false;  // (a device with few CUs: the step kernels run instead)
     coop_gate_launch(c, a.need, a.sync, a.hdr, 2 * g * 5);
     if (small) hipLaunchKernelGGL((k_qrb_coop<T, NE_SMALL, 4>), dim3((unsigned)g), dim3(512), 0, c->stream, a);
     else hipLaunchKernelGGL((k_qrb_coop<T, NE_BIG, WPE_BIG>), dim3((unsigned)g), dim3(512), 0, c->stream, a);
+    return true;
 }
 
 // One factorization as a resumable job: issue() enqueues a panel's kernels and the read-back of its state, finish() -- once
@@ -1345,11 +1347,13 @@ void qrb_issue(BlockedQrcpJob<T> *J) {
         QrbCoopArgs<T> a = J->coop;
         a.j0 = (int)j0;
         a.nbp = nbp;
-        qrb_coop_launch<T>(c, a, g, (int)(m - j0));
-        RC_HIP(hipMemcpyAsync(J->host_st, J->st, sizeof(QrbState), hipMemcpyDeviceToHost, c->stream));
-        J->coop_issued = true;
-        J->cw_issued = cw_c;
-        return;
+        if (qrb_coop_launch<T>(c, a, g, (int)(m - j0))) {
+            RC_HIP(hipMemcpyAsync(J->host_st, J->st, sizeof(QrbState), hipMemcpyDeviceToHost, c->stream));
+            J->coop_issued = true;
+            J->cw_issued = cw_c;
+            return;
+        }
+        J->coop_ready = false;  // does not fit this device: step kernels from here on (they redo the selection)
     }
     // A panel is ~65 dependent launches at ~3.5 us of host time each: replay them from a hipGraph, cached on the context
     // under everything the launches bake in (the arena hands out the same addresses for the same call sequence, so a

@@ -465,11 +465,12 @@ static void coop_shape(int64_t m, int64_t n, int *ne, int *cpg, int *cpw, int *g
 }
 
 template <typename T>
-bool wide_coop_supported(int64_t m, int64_t n) {
+bool wide_coop_supported(int64_t m, int64_t n, int device) {
     if (!(m >= 2 && m <= 256 && n >= 4 * m && n >= 256)) return false;
     int ne, cpg, cpw, g;
     coop_shape<T>(m, n, &ne, &cpg, &cpw, &g);
-    return g >= 1 && g <= kCoopMaxWgs && n < (int64_t)1 << 30;
+    // (a device with few CUs -- a partitioned one -- cannot hold the launch: the non-cooperative path runs instead)
+    return g >= 1 && g <= kCoopMaxWgs && n < (int64_t)1 << 30 && 2u * (unsigned)g <= coop_budget_units(device);
 }
 
 // w: m x n column-major input (left untouched); wf: m x n column-major output, the factorization in
@@ -482,7 +483,7 @@ void geqp3_wide_coop(rc_context *c, Mat<T> w, Mat<T> wf, int64_t kmax, int64_t *
     kmax = std::min(kmax, std::min(m, n));
     int ne, cpg, cpw, g;
     coop_shape<T>(m, n, &ne, &cpg, &cpw, &g);
-    RC_REQUIRE(wide_coop_supported<T>(m, n), RC_INVALID_ARGUMENT, "geqp3_wide_coop: unsupported shape");
+    RC_REQUIRE(wide_coop_supported<T>(m, n, c->device), RC_INVALID_ARGUMENT, "geqp3_wide_coop: unsupported shape");
     ProfScope ps(c, "op:geqp3_wide_coop %lldx%lld k=%lld wgs=%d", (long long)m, (long long)n, (long long)kmax, g);
     WqCoopArgs<T> a;
     a.w = w;
@@ -509,8 +510,8 @@ void geqp3_wide_coop(rc_context *c, Mat<T> w, Mat<T> wf, int64_t kmax, int64_t *
 #ifdef RC_COOP_TIMING
 extern "C" void rc_debug_coop_timing(unsigned long long *out) { (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_coop_dbg), 8 * sizeof(unsigned long long)); }
 #endif
-template bool wide_coop_supported<double>(int64_t, int64_t);
-template bool wide_coop_supported<float>(int64_t, int64_t);
+template bool wide_coop_supported<double>(int64_t, int64_t, int);
+template bool wide_coop_supported<float>(int64_t, int64_t, int);
 template void geqp3_wide_coop<double>(rc_context *, Mat<double>, Mat<double>, int64_t, int64_t *, double *, int *);
 template void geqp3_wide_coop<float>(rc_context *, Mat<float>, Mat<float>, int64_t, int64_t *, float *, int *);
 

@@ -254,7 +254,7 @@ void qrcp_core(rc_context *c, Mat<T> w, int64_t k, bool pivot, Mat<T> q, Mat<T> 
     if (c->opt_tsqr && k >= 1 && tsqr_supported<T>(w.rows, n)) {
         if (run_certified(c, [&](int *flag) { qrcp_tall_fast<T>(c, w, k, pivot, q, r, ind, flag); })) return;
     }
-    if (c->opt_wide_coop && pivot && k >= 1 && wide_coop_supported<T>(w.rows, n)) {
+    if (c->opt_wide_coop && pivot && k >= 1 && wide_coop_supported<T>(w.rows, n, c->device)) {
         T *tau = c->alloc<T>((size_t)k);
         Mat<T> wf = tmp_colmajor<T>(c, w.rows, n);
         if (run_certified(c, [&](int *flag) { geqp3_wide_coop<T>(c, w, wf, k, ind, tau, flag); })) {

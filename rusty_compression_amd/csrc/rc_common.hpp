@@ -231,7 +231,7 @@ template <typename T> bool wide_lazy_supported(int64_t m, int64_t n);
 template <typename T> void geqp3_wide_lazy(rc_context *c, Mat<T> b, int64_t kmax, int64_t *jpvt, Mat<T> q, Mat<T> r);
 // short-wide matrices, one cooperative launch (kernels_wqcoop.hip): wf gets the ?geqp3 output format;
 // flag gets bit 4 (w is never written) when the workgroups could not all become resident in time
-template <typename T> bool wide_coop_supported(int64_t m, int64_t n);
+template <typename T> bool wide_coop_supported(int64_t m, int64_t n, int device);
 template <typename T> void geqp3_wide_coop(rc_context *c, Mat<T> w, Mat<T> wf, int64_t kmax, int64_t *jpvt, T *tau, int *flag);
 void coop_prepare(int device);
 // device-wide budget of the cooperative kernels, in half compute units (kernels_wqcoop.hip)
