@@ -621,7 +621,7 @@ static void launch_cfg(rc_context *c, GemmArgs<T> g, int target_wgs = 0, int min
 }
 
 template <int ALAY, int BLAY, int BM, int BN, int BK, int WM, int WN, int VEC, int ORIENT, int GLDS = 0>
-static void launch_f64q(rc_context *c, GemmArgs<double> g) {
+static void launch_f64q(rc_context *c, GemmArgs<double> g, int target_wgs = 0) {
     typedef double T;
     constexpr int NT = WM * WN * 64;
     typedef TileStager<T, ALAY, BM, BK, NT, VEC> StA;
@@ -636,7 +636,7 @@ static void launch_f64q(rc_context *c, GemmArgs<double> g) {
     // amortise its prologue / slab write, and the reduction reads 4x less than with 128 slabs
     static const int target_big = env_int("RC_GEMM_TARGET_WGS", 256), target_small = env_int("RC_GEMM_SMALL_TARGET", 32);
     // with many compressions in flight (RC_OPT_CONCURRENCY_HINT) the other streams fill the chip: wide products stay un-split
-    const int target = tiles >= 8 ? (c->opt_lanes >= 8 && tiles >= 32 ? 1 : target_big) : target_small;
+    const int target = tiles >= 8 ? (c->opt_lanes >= 8 && tiles >= 32 ? 1 : (target_wgs > 0 ? target_wgs : target_big)) : target_small;
     int splits = 1;
     const int64_t ksteps = cdiv(g.K, BK);
     while (tiles * splits < target && splits < 128 && ksteps / (splits * 2) >= (tiles >= 32 ? 16 : 4)) splits *= 2;
@@ -681,7 +681,7 @@ static bool launch_shape_f64q(rc_context *c, const GemmArgs<double> &g) {
     // Skinny shapes: the narrow dimension is padded to the micro-tile granularity only -- 16 along the
     // "shared" operand's side, 4 along the other (ORIENT picks which) -- so N = 133 costs 136, M = 128 costs 128.
     // (N = 133 through ORIENT 1 / BN = 136 measured slower than BN = 144: 34 B-fragment reads per sub-step.)
-    static const int vn = env_int("RC_GEMM_F64Q_N", 3), vm = env_int("RC_GEMM_F64Q_M", 3), smallk = env_int("RC_GEMM_SMALLK", 1);
+    static const int vn = env_int("RC_GEMM_F64Q_N", 3), vm = env_int("RC_GEMM_F64Q_M", 3), smallk = env_int("RC_GEMM_SMALLK", 1), two_wg = env_int("RC_GEMM_SKETCH_2WG", 0);
     if (g.M <= 144 && g.N <= 144 && g.M > 80 && g.N > 80) launch_f64q<ALAY, BLAY, 144, 144, 16, 3, 3, VEC, 0>(c, g);
     else if (g.N <= 80) launch_f64q<ALAY, BLAY, 256, 80, 16, 8, 1, VEC, 0>(c, g);
     else if (g.N <= 128 && vn == 3) launch_f64q<ALAY, BLAY, 256, 128, 16, 8, 1, VEC, 0>(c, g);
@@ -697,6 +697,10 @@ static bool launch_shape_f64q(rc_context *c, const GemmArgs<double> &g) {
         if (g.M <= 128) launch_f64q<ALAY, BLAY, 128, 128, 16, 1, 8, VEC, 1>(c, g);
         else launch_f64q<ALAY, BLAY, 136, 128, 16, 2, 4, VEC, 0>(c, g);
     }
+    else if (g.M <= 128 && g.M > 80 && vm == 3 && ALAY == 1 && BLAY == 0 && VEC == 2 && two_wg && g.K % 16 == 0 && g.sam == 1 && g.sbn == 1 && g.N >= 1024) {
+        // the projection on two 4-wave workgroups per CU (128 x 128 tiles, 128 x 32 wave tiles; k_gemm_f64a)
+        launch_f64q<ALAY, BLAY, 128, 128, 16, 1, 4, VEC, 1>(c, g, 512);
+    }
     else if (g.M <= 128 && vm == 3) {
         static const int glds = env_int("RC_GEMM_GLDS", 2);  // 0: register staging, 1: B tile direct to LDS, 2: A tile too, 3: + three LDS buffers (no gain measured)
         const bool direct = glds && BLAY == 0 && VEC == 2 && g.N % 256 == 0 && g.K % 16 == 0 && g.sbn == 1 && g.sbk % 2 == 0 &&
@@ -710,6 +714,11 @@ static bool launch_shape_f64q(rc_context *c, const GemmArgs<double> &g) {
             if (direct) { launch_f64q<ALAY, BLAY, 128, 256, 16, 1, 8, VEC, 1, 1>(c, g); return true; }
         }
         launch_f64q<ALAY, BLAY, 128, 256, 16, 1, 8, VEC, 1>(c, g);
+    }
+    else if (g.M <= 136 && g.M > 128 && vm == 3 && ALAY == 1 && BLAY == 1 && VEC == 2 && two_wg && g.N % 128 == 0 && g.K % 16 == 0 && g.sam == 1 && g.sbk == 1) {
+        // the sketch on two 4-wave workgroups per CU (136 x 128 tiles, the same 68 x 64 wave tiles; k_gemm_f64a): each one's
+        // barrier and copy issue hide behind the other's MFMAs; a lone product is split until 512 workgroups exist
+        launch_f64q<ALAY, BLAY, 136, 128, 16, 2, 2, VEC, 0>(c, g, 512);
     }
     else if (g.M <= 136 && vm == 3) {  // 68 x 64 wave tiles: 17 + 4 fragment reads per 68 MFMAs
         static const int glds = env_int("RC_GEMM_GLDS", 2);

@@ -17,6 +17,9 @@
 //     whose order is pinned with sched_group_barrier.
 #include "rc_gemm.hpp"
 
+#include <type_traits>
+#include <utility>
+
 namespace rc {
 
 typedef double pdouble2_t __attribute__((ext_vector_type(2)));
@@ -227,23 +230,27 @@ typedef __attribute__((address_space(3))) void *lds_ptr_t;
 // Operand stored with its ROW index contiguous (unit row stride, `sk` between reduction indices): LDS image [BK][P],
 // one piece = 128 consecutive rows of one reduction index.  R <= 128 -> P = 144; R <= 256 -> P = 272 (the second piece
 // of a row is always copied whole -- 1 KiB -- so the pitch covers 256 rows; lanes beyond the matrix re-read its last pair).
-template <int R, int BK, int NT>
+template <int R, int BK, int NT, bool MASKTAIL = false>
 struct DirectRows {
-    static constexpr int PIECES_ROW = (R + 127) / 128;
-    static constexpr int P = R <= 128 ? pp_pitch16(128) : pp_pitch16(256);
+    // MASKTAIL (tiles of 128 < R <= 144 rows): the rows beyond the first piece go in a piece that only the lanes carrying them
+    // copy, so the pitch is pitch16(R) = 144 instead of 272 (18 KB per stage instead of 35) and the copy moves 64 bytes instead
+    // of 1 KiB per reduction index
+    static constexpr int PIECES_ROW = MASKTAIL ? 1 : (R + 127) / 128;
+    static constexpr int TAIL = MASKTAIL ? R - 128 : 0;
+    static constexpr int P = MASKTAIL ? pp_pitch16(R) : (R <= 128 ? pp_pitch16(128) : pp_pitch16(256));
     static constexpr int ELEMS = BK * P;
     static constexpr int NW = NT / 64;
     static constexpr int PER_WAVE = BK * PIECES_ROW / NW;
-    static_assert(BK * PIECES_ROW % NW == 0 && PER_WAVE >= 1 && R <= 256, "direct-to-LDS tile (row-contiguous operand): shape");
-    uint32_t voff[PIECES_ROW];
+    static_assert(BK * PIECES_ROW % NW == 0 && PER_WAVE >= 1 && R <= 256 && (!MASKTAIL || (R > 128 && R <= 144 && TAIL % 2 == 0)), "direct-to-LDS tile (row-contiguous operand): shape");
+    uint32_t voff[PIECES_ROW + (MASKTAIL ? 1 : 0)];
     uint32_t sk8;
     __device__ inline void init(int64_t rows_left, int64_t sk, int lane) {
         const int rclamp = ((int)min((int64_t)R, rows_left) - 1) & ~1;
 #pragma unroll
-        for (int h = 0; h < PIECES_ROW; ++h) voff[h] = (uint32_t)(min(h * 128 + 2 * lane, rclamp) * 8);
+        for (int h = 0; h < PIECES_ROW + (MASKTAIL ? 1 : 0); ++h) voff[h] = (uint32_t)(min(h * 128 + 2 * lane, rclamp) * 8);
         sk8 = (uint32_t)(sk * 8);
     }
-    __device__ inline void copy(__amdgpu_buffer_rsrc_t rsrc, uint32_t tile_off, double *stage, int wave_u) const {
+    __device__ inline void copy(__amdgpu_buffer_rsrc_t rsrc, uint32_t tile_off, double *stage, int wave_u, int lane = 0) const {
         static_assert(PER_WAVE % PIECES_ROW == 0, "a wave copies whole rows");
 #pragma unroll
         for (int i = 0; i < PER_WAVE; ++i) {
@@ -251,6 +258,10 @@ struct DirectRows {
             const int h = i % PIECES_ROW;                                       // compile time
             const uint32_t soff = __builtin_amdgcn_readfirstlane(tile_off + kk * sk8);
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_ptr_t)(stage + kk * P + h * 128), 16, voff[h], soff, 0, 0);
+            if constexpr (MASKTAIL) {
+                if (lane < TAIL / 2)  // a lane's 16 bytes land at lane * 16 behind the piece's base
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_ptr_t)(stage + kk * P + 128), 16, voff[1], soff, 0, 0);
+            }
         }
     }
     // fragment address (doubles) of row r, reduction index k
@@ -416,6 +427,189 @@ __global__ __launch_bounds__(WM *WN * 64) void k_gemm_f64d(GemmArgs<double> g) {
         }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// The sketch shape with a HAND-ORDERED main loop.  Same tiles, copies and barrier placement as k_gemm_f64d (A row-contiguous,
+// B K-contiguous and swizzled, 4-row x 16-column micro tiles, 16-deep K tiles), but every LDS read and MFMA of the loop is an
+// `asm volatile` statement, so the instruction order is the written one and the registers live exactly as long as written:
+//   sub-step s:  4 B-fragment reads for s + 1 | for i = 0..TM-1: [wait] 4 MFMAs on A-fragment i, then the read of A-fragment i
+//                for s + 1 INTO THE SAME variable (one rotating A set, B double buffered: 50 fragment registers instead of 84)
+// LDS data return in issue order and 20 reads are always issued between a fragment's read and its use, so `s_waitcnt
+// lgkmcnt(15)` in front of every MFMA group is enough (the counter has 4 bits) and never stalls.  With the masked tail copy
+// (DirectRows<..., true>) a stage is 34.8 KB, and with 4 waves per workgroup two workgroups share a CU: each one's barrier and
+// copy issue hide behind the other's MFMAs.
+// ---------------------------------------------------------------------------------------------------------------------
+// single instructions as ordered statements (clang does not accept captured variables as asm operands inside lambdas, so the
+// compile-time loops are fold expressions over these function templates)
+template <int OFF>
+__device__ inline void asm_lds_read(double &dst, uint32_t addr) { asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(OFF)); }
+__device__ inline void asm_mfma(double &acc, const double &a, const double &b) { asm volatile("v_mfma_f64_4x4x4_4b_f64 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(b)); }
+template <int TN, int OFF0, int JSTRIDE, int... J>
+__device__ inline void asm_read_b(double (&fb)[TN], uint32_t vb, std::integer_sequence<int, J...>) { (asm_lds_read<OFF0 + J * JSTRIDE>(fb[J], vb), ...); }
+template <int TM, int OFF0, int ISTRIDE, int... I>
+__device__ inline void asm_read_a(double (&fa)[TM], uint32_t va, std::integer_sequence<int, I...>) { (asm_lds_read<OFF0 + I * ISTRIDE>(fa[I], va), ...); }
+template <int TN, int... J>
+__device__ inline void asm_mfma_row(double (&acc)[TN], const double &a, const double (&fb)[TN], std::integer_sequence<int, J...>) { (asm_mfma(acc[J], a, fb[J]), ...); }
+// one A fragment: wait, TN MFMAs, re-read the fragment for the next sub-step into the same variable
+template <int TM, int TN, int OFF0, int ISTRIDE, int I>
+__device__ inline void asm_group(double (&acc)[TM][TN], double (&fa)[TM], const double (&fb)[TN], uint32_t va) {
+    asm volatile("s_waitcnt lgkmcnt(15)" ::: "memory");
+    asm_mfma_row<TN>(acc[I], fa[I], fb, std::make_integer_sequence<int, TN>{});
+    asm_lds_read<OFF0 + I * ISTRIDE>(fa[I], va);
+}
+template <int TM, int TN, int OFF0, int ISTRIDE, int... I>
+__device__ inline void asm_groups(double (&acc)[TM][TN], double (&fa)[TM], const double (&fb)[TN], uint32_t va, std::integer_sequence<int, I...>) {
+    (asm_group<TM, TN, OFF0, ISTRIDE, I>(acc, fa, fb, va), ...);
+}
+
+// BLAY 1 / ORIENT 0: the sketch (B K-contiguous, swizzled image; 4-row x 16-column micro tiles)
+// BLAY 0 / ORIENT 1: the projection (B N-contiguous, padded image; 16-row x 4-column micro tiles)
+template <int BLAY, int ORIENT, int BM, int BN, int WM, int WN, bool MASKTAIL>
+__global__ __launch_bounds__(WM *WN * 64, 2) void k_gemm_f64a(GemmArgs<double> g) {
+    constexpr int BK = 16;
+    constexpr int NT = WM * WN * 64;
+    constexpr int WR = BM / WM, WC = BN / WN;
+    constexpr int AM = ORIENT == 0 ? 4 : 16, BNW = ORIENT == 0 ? 16 : 4;
+    constexpr int TM = WR / AM, TN = WC / BNW;
+    static_assert((BLAY == 1 && ORIENT == 0) || (BLAY == 0 && ORIENT == 1), "instantiated pairings");
+    static_assert(WR % AM == 0 && WC % BNW == 0 && TM + TN - 1 >= 15, "wave tile shape (and at least 15 reads between a fragment's read and its use)");
+    typedef DirectRows<BM, BK, NT, MASKTAIL> SA;
+    typedef DirectRows<BN, BK, NT> SBR;
+    typedef DirectK<BN, BK, NT> SBK;
+    constexpr int PA = SA::P, PB = SBR::P;
+    constexpr int A_ELEMS = SA::ELEMS, STAGE = SA::ELEMS + (BLAY == 0 ? SBR::ELEMS : SBK::ELEMS);
+
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    double *smem = reinterpret_cast<double *>(smem_raw);
+    const uint32_t lds0 = (uint32_t)reinterpret_cast<uintptr_t>((__attribute__((address_space(3))) char *)smem_raw);
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    const int wm = wave / WN, wn = wave % WN;
+    const int lk = lane >> 4;
+    const int la = ORIENT == 0 ? (lane & 3) : (lane & 15);
+    const int lbn = ORIENT == 0 ? (lane & 15) : (lane & 3);
+
+    const int ntiles = g.tiles_m * g.tiles_n;
+    int bid = blockIdx.x;
+    {
+        const int q = ntiles / 8, r = ntiles % 8, xcd = bid % 8, idx = bid / 8;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    const int tile_n = bid % g.tiles_n, tile_m = bid / g.tiles_n;
+    const int64_t m0 = (int64_t)tile_m * BM, n0 = (int64_t)tile_n * BN;
+    const int split = blockIdx.y;
+    const int64_t kbeg = (int64_t)split * g.kchunk;
+    const int64_t kend = min(g.K, kbeg + g.kchunk);
+    const int nk = (int)((kend - kbeg) / BK);
+
+    double acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = 0.0;
+
+    SA sa;
+    SBR sbr;
+    SBK sbk;
+    sa.init(g.M - m0, g.sak, lane);
+    if (BLAY == 0) sbr.init(g.N - n0, g.sbk, lane);
+    else sbk.init(g.sbn, lane);
+    const __amdgpu_buffer_rsrc_t a_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<double *>(g.a + m0 * g.sam + kbeg * g.sak), 0, 0x7fffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t b_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<double *>(g.b + n0 * g.sbn + kbeg * g.sbk), 0, 0x7fffffff, 0x00020000);
+    const uint32_t a_step = (uint32_t)(BK * g.sak * 8), b_step = (uint32_t)(BK * g.sbk * 8);
+    auto copy_tile = [&](int t, double *stage) {
+        sa.copy(a_rsrc, t * a_step, stage, wave_u, lane);
+        if (BLAY == 0) sbr.copy(b_rsrc, t * b_step, stage + A_ELEMS, wave_u, lane);
+        else sbk.copy(b_rsrc, t * b_step, stage + A_ELEMS, wave_u);
+    };
+
+    // LDS byte addresses of this lane's fragments inside stage 0.  A fragment i of sub-step s: + (s * 4 * PA + i * AM) * 8.
+    // B, K-contiguous image: row base + ((chunk pair) ^ 32 s), fragment j + j * 16 rows; N-contiguous image: + (s * 4 * PB + j * BNW) * 8.
+    const uint32_t a_addr = lds0 + (uint32_t)(lk * PA + wm * WR + la) * 8;
+    const uint32_t b_addr = BLAY == 1 ? lds0 + (uint32_t)(A_ELEMS + (wn * WC + lbn) * BK + (lk & 1)) * 8
+                                      : lds0 + (uint32_t)(A_ELEMS + lk * PB + wn * WC + lbn) * 8;
+    const uint32_t swz8 = BLAY == 1 ? (uint32_t)((((lk >> 1) ^ (lbn >> 1)) & 7) * 16) : 0u;
+    constexpr int ISTRIDE = AM * 8, AKS = 4 * PA * 8;
+    constexpr int JSTRIDE = BLAY == 1 ? 16 * BK * 8 : BNW * 8, BKS = BLAY == 1 ? 0 : 4 * PB * 8;
+    auto b_base = [&](uint32_t stage_off, int ks) -> uint32_t { return BLAY == 1 ? b_addr + stage_off + (swz8 ^ (uint32_t)(ks * 32)) : b_addr + stage_off; };
+
+    copy_tile(0, smem);
+    copy_tile(min(1, nk - 1), smem + STAGE);
+    asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+
+    double fa[TM], fb[2][TN];
+    asm_read_b<TN, 0, JSTRIDE>(fb[0], b_base(0, 0), std::make_integer_sequence<int, TN>{});
+    asm_read_a<TM, 0, ISTRIDE>(fa, a_addr, std::make_integer_sequence<int, TM>{});
+
+    for (int it = 0; it < nk; ++it) {
+        const uint32_t cur_off = (uint32_t)((it & 1) * STAGE * 8), nxt_off = (uint32_t)(((it & 1) ^ 1) * STAGE * 8);
+        // sub-steps 0 .. 2: the next fragments come from the same stage; sub-step 3: from sub-step 0 of the other stage
+        {
+            asm_read_b<TN, 1 * BKS, JSTRIDE>(fb[1], b_base(cur_off, 1), std::make_integer_sequence<int, TN>{});
+            asm_groups<TM, TN, 1 * AKS, ISTRIDE>(acc, fa, fb[0], a_addr + cur_off, std::make_integer_sequence<int, TM>{});
+        }
+        {
+            asm_read_b<TN, 2 * BKS, JSTRIDE>(fb[0], b_base(cur_off, 2), std::make_integer_sequence<int, TN>{});
+            asm_groups<TM, TN, 2 * AKS, ISTRIDE>(acc, fa, fb[1], a_addr + cur_off, std::make_integer_sequence<int, TM>{});
+        }
+        {
+            asm_read_b<TN, 3 * BKS, JSTRIDE>(fb[1], b_base(cur_off, 3), std::make_integer_sequence<int, TN>{});
+            asm_groups<TM, TN, 3 * AKS, ISTRIDE>(acc, fa, fb[0], a_addr + cur_off, std::make_integer_sequence<int, TM>{});
+            // tile it + 1 has landed in the other stage; this wave's reads of the current one are complete
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            copy_tile(min(it + 2, nk - 1), smem + (it & 1) * STAGE);
+        }
+        {
+            asm_read_b<TN, 0, JSTRIDE>(fb[0], b_base(nxt_off, 0), std::make_integer_sequence<int, TN>{});
+            asm_groups<TM, TN, 0, ISTRIDE>(acc, fa, fb[1], a_addr + nxt_off, std::make_integer_sequence<int, TM>{});
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");  // outstanding (redundant) copies and prefetched fragments
+
+    const int er = ORIENT == 0 ? (lane >> 4) : (((lane >> 2) & 3) * 4 + (lane >> 4));
+    const int ec = ORIENT == 0 ? (lane & 15) : (lane & 3);
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int64_t gm = m0 + wm * WR + i * AM + er;
+            const int64_t gn = n0 + wn * WC + j * BNW + ec;
+            if (gm < g.M && gn < g.N) {
+                const double v = acc[i][j];
+                if (g.splits > 1) {
+                    g.partial[((int64_t)split * g.M + gm) * g.N + gn] = v;
+                } else {
+                    double *cp = g.c + gm * g.scm + gn * g.scn;
+                    *cp = g.beta == 0.0 ? g.alpha * v : g.alpha * v + g.beta * (*cp);
+                }
+            }
+        }
+}
+
+template <int BLAY, int ORIENT, int BM, int BN, int WM, int WN, bool MASKTAIL>
+static bool launch_a(rc_context *c, const GemmArgs<double> &g) {
+    constexpr int NT = WM * WN * 64;
+    constexpr size_t lds = 2 * (size_t)(DirectRows<BM, 16, NT, MASKTAIL>::ELEMS + (BLAY == 0 ? DirectRows<BN, 16, NT>::ELEMS : DirectK<BN, 16, NT>::ELEMS)) * sizeof(double);
+    static_assert(lds <= 160 * 1024, "tile does not fit LDS");
+    if (g.sam != 1) return false;
+    if (BLAY == 0 ? g.sbn != 1 : (g.sbk != 1 || g.N % BN != 0)) return false;
+    const int64_t a_span = ((int64_t)256 * g.sam + g.kchunk * g.sak + 2) * 8;
+    const int64_t b_span = ((int64_t)BN * g.sbn + g.kchunk * g.sbk + 2) * 8;
+    if (a_span >= (1ll << 31) || b_span >= (1ll << 31) || g.sak < 0 || g.sbn < 0 || g.sbk < 0) return false;
+    auto kern = k_gemm_f64a<BLAY, ORIENT, BM, BN, WM, WN, MASKTAIL>;
+    static bool attr_set[64] = {};
+    if (lds > 48 * 1024 && !attr_set[c->device & 63]) {
+        RC_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_set[c->device & 63] = true;
+    }
+    char nm[128];
+    snprintf(nm, sizeof(nm), "k_gemm_f64a<%d,%d,%d,%d,%d,%d,%s>", BLAY, ORIENT, BM, BN, WM, WN, MASKTAIL ? "true" : "false");
+    c->last_gemm_kernel = nm;
+    ProfScope ps(c, "kernel:k_gemm_mfma<f64> M=%lld N=%lld K=%lld", (long long)g.M, (long long)g.N, (long long)g.K);
+    hipLaunchKernelGGL(kern, dim3((unsigned)(g.tiles_m * g.tiles_n), (unsigned)g.splits), dim3(NT), lds, c->stream, g);
+    return true;
+}
+
 template <int BLAY, int BM, int BN, int BK, int WM, int WN, int ORIENT>
 static bool launch_d(rc_context *c, const GemmArgs<double> &g) {
     constexpr int NT = WM * WN * 64;
@@ -489,6 +683,12 @@ bool gemm_f64p_launch(rc_context *c, const GemmArgs<double> &g, int alay, int bl
     // register-staged instance spills), 2 = also for the projection (325 us against 321 us register-staged), 0 = never
     static const int direct = [] { const char *e = getenv("RC_GEMM_PIPE_DIRECT"); return e ? atoi(e) : 1; }();
     if (direct && alay == 1 && bk == 16) {
+        // hand-ordered main loop (k_gemm_f64a) on two 4-wave workgroups per CU, where kernels_gemm.hip chose 128-column tiles for it
+        static const int wide_asm = [] { const char *e = getenv("RC_GEMM_PIPE_ASM"); return e ? atoi(e) : 1; }();  // 0: the compiler-scheduled loops (k_gemm_f64d / k_gemm_f64p)
+        if (wide_asm && blay == 1 && bm == 136 && bn == 256 && wm == 2 && wn == 4 && orient == 0 && launch_a<1, 0, 136, 256, 2, 4, true>(c, g)) return true;
+        if (wide_asm && blay == 0 && bm == 128 && bn == 256 && wm == 1 && wn == 8 && orient == 1 && launch_a<0, 1, 128, 256, 1, 8, false>(c, g)) return true;
+        if (blay == 1 && bm == 136 && bn == 128 && wm == 2 && wn == 2 && orient == 0 && launch_a<1, 0, 136, 128, 2, 2, true>(c, g)) return true;
+        if (blay == 0 && bm == 128 && bn == 128 && wm == 1 && wn == 4 && orient == 1 && launch_a<0, 1, 128, 128, 1, 4, false>(c, g)) return true;
         if (blay == 1 && bm == 136 && bn == 256 && wm == 2 && wn == 4 && orient == 0 && launch_d<1, 136, 256, 16, 2, 4, 0>(c, g)) return true;
         if (direct >= 2 && blay == 0 && bm == 128 && bn == 256 && wm == 1 && wn == 8 && orient == 1 && launch_d<0, 128, 256, 16, 1, 8, 1>(c, g)) return true;
     }
@@ -503,5 +703,9 @@ bool gemm_f64p_launch(rc_context *c, const GemmArgs<double> &g, int alay, int bl
 namespace rc {
 // (explicit: clang did not emit the host stub of the second instantiation from its use inside the `&&` chain above)
 template __global__ void k_gemm_f64d<1, 136, 256, 16, 2, 4, 0>(GemmArgs<double>);
+template __global__ void k_gemm_f64a<1, 0, 136, 128, 2, 2, true>(GemmArgs<double>);
+template __global__ void k_gemm_f64a<1, 0, 136, 256, 2, 4, true>(GemmArgs<double>);
+template __global__ void k_gemm_f64a<0, 1, 128, 256, 1, 8, false>(GemmArgs<double>);
+template __global__ void k_gemm_f64a<0, 1, 128, 128, 1, 4, false>(GemmArgs<double>);
 template __global__ void k_gemm_f64d<0, 128, 256, 16, 1, 8, 1>(GemmArgs<double>);
 }
