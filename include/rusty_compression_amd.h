@@ -154,7 +154,8 @@ rc_status rc_set_option(rc_context *ctx, int32_t option, int64_t value);
  * (both: tall-skinny fast path inside a graph, where no fallback is possible), 4 cooperative short-wide QR could not get
  * its workgroups resident, 8 the right-vector workgroup of the Jacobi SVD never saw its producer within the spin bound,
  * 16 a Jacobi SVD used up its sweep budget before converging (eager calls as well: the factors are then accurate to the
- * last sweep's rotation angles only).  0 = every result stands. */
+ * last sweep's rotation angles only), 32 an index handed to a gather (a permutation entry, a column index) was outside the
+ * source: the affected outputs are zero instead of whatever a wild address held.  0 = every result stands. */
 rc_status rc_get_health(rc_context *ctx, int32_t *word);
 
 /* Stage / kernel timers: HIP events recorded on the context's stream around the

@@ -736,6 +736,7 @@ __global__ __launch_bounds__(512, WPE) void k_qrb_coop(QrbCoopArgs<T> a) {
     __shared__ int bc[6];
     __shared__ int sh_exit;
     __shared__ int ov_pos[kNB], ov_col[kNB], ov_n;
+    __shared__ int ov_orig[kNB];  // who sat at positions j0 .. j0+nbp-1 when the panel started (workgroup 0)
     // (wave-uniform values are forced into scalar registers: the per-wave roles below must compile to scalar branches, not
     // to exec-masked selects that keep two copies of the register-resident column alive)
     const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -753,6 +754,10 @@ __global__ __launch_bounds__(512, WPE) void k_qrb_coop(QrbCoopArgs<T> a) {
     const bool too_many = ncand > NW * G;
     bool aborted = ab0 != 0u || too_many;
     if (tid == 0) { sh_exit = 0; ov_n = 0; }
+    // Snapshot of the panel's positions, taken BEFORE any step: the write-back at the end of this kernel stores into jpvt, and a
+    // workgroup that is through its last step may do so while workgroup 0 is still in that step's bookkeeping (it used to read
+    // jpvt[j] there and could see the pivot just written by its owner: one duplicated column in the permutation).
+    if (wg == 0 && tid < kNB) ov_orig[tid] = tid < a.nbp ? (int)a.P.jpvt[j0 + tid] : -1;
 
     const int ci = wg * NW + wv;
     const bool have = __builtin_amdgcn_readfirstlane((int)(ci < ncand && !aborted)) != 0;
@@ -1042,7 +1047,7 @@ __global__ __launch_bounds__(512, WPE) void k_qrb_coop(QrbCoopArgs<T> a) {
                 int oldc = -1, slot = -1;
                 for (int i = 0; i < ov_n; ++i)
                     if (ov_pos[i] == j) { oldc = ov_col[i]; slot = i; }
-                if (oldc < 0) { oldc = (int)a.P.jpvt[j]; slot = ov_n; ov_n = ov_n + 1; }
+                if (oldc < 0) { oldc = ov_orig[jj]; slot = ov_n; ov_n = ov_n + 1; }
                 ov_pos[slot] = wp;
                 ov_col[slot] = oldc;
             }
@@ -1174,6 +1179,16 @@ __global__ __launch_bounds__(256) void k_qrb_block_update(Mat<T> w, int row0, in
 #pragma unroll
         for (int i = 0; i < RPT; ++i) x[i] = xn[i];
         c = cn;
+    }
+}
+
+// diagnostic (RC_QRCP_CHECK=1): jpvt must be a permutation of 0 .. n-1 and pos its inverse; counts the violations
+__global__ __launch_bounds__(256) void k_qrb_check_perm(const int64_t *jpvt, const int *pos, int n, int *mark, int *bad) {
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+        const int64_t c = jpvt[i];
+        if (c < 0 || c >= n) { atomicAdd(bad, 1); continue; }
+        if (atomicAdd(mark + c, 1) != 0) atomicAdd(bad + 1, 1);
+        if (pos[c] != i) atomicAdd(bad + 2, 1);
     }
 }
 
@@ -1409,6 +1424,21 @@ bool qrb_finish(BlockedQrcpJob<T> *J) {
     }
     const int kb = h.stopped ? h.kb : J->nbp;
     RC_REQUIRE(kb >= 1 && kb <= J->nbp, RC_PIVOTED_QR_ERROR, "geqp3_blocked: panel at %lld made %d steps", (long long)j0, kb);
+    static const int check = env_int_b("RC_QRCP_CHECK", 0);
+    if (check) {
+        ArenaMark mk(c);
+        int *mark = c->alloc<int>((size_t)n + 4);
+        RC_HIP(hipMemsetAsync(mark, 0, ((size_t)n + 4) * sizeof(int), c->stream));
+        hipLaunchKernelGGL(k_qrb_check_perm, dim3((unsigned)std::min<int64_t>(cdivb(n, 256), 1024)), dim3(256), 0, c->stream, J->jpvt, J->pos, (int)n, mark, mark + n);
+        int bad[3] = {0, 0, 0};
+        RC_HIP(hipMemcpyAsync(bad, mark + n, sizeof(bad), hipMemcpyDeviceToHost, c->stream));
+        RC_HIP(hipStreamSynchronize(c->stream));
+        if (bad[0] || bad[1] || bad[2]) {
+            fprintf(stderr, "RC_QRCP_CHECK: INVALID permutation after panel j0=%lld kb=%d/%d coop=%d pad0=%d ncand=%d noncand=%d stop_tau=%d: out of range %d, duplicates %d, pos mismatches %d\n",
+                    (long long)j0, kb, J->nbp, coop ? 1 : 0, h.pad0, h.ncand, h.have_noncand, h.stop_tau, bad[0], bad[1], bad[2]);
+            fail(RC_PIVOTED_QR_ERROR, "geqp3_blocked: permutation invalid after the panel at %lld", (long long)j0);
+        }
+    }
     const int64_t rows = m - j0;
     const bool last = j0 + kb >= J->kmax;
     Mat<T> w = J->w;

@@ -171,14 +171,21 @@ void scale_rows(rc_context *c, const T *s, Mat<T> src, Mat<T> dst) {
 // dst[:, j] = src[:, idx[j]]  (row gathers are expressed by transposed views)
 // /root/reference/src/permutation.rs:100-139
 template <typename T>
-__global__ __launch_bounds__(256) void k_gather_cols(Mat<T> src, const int64_t *idx, Mat<T> dst) {
+__global__ __launch_bounds__(256) void k_gather_cols(Mat<T> src, const int64_t *idx, Mat<T> dst, int *health) {
     const bool col_fast = (dst.cs <= dst.rs);
     const int64_t total = dst.rows * dst.cols;
     for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
         int64_t i, j;
         if (col_fast) { i = e / dst.cols; j = e - i * dst.cols; }
         else { j = e / dst.rows; i = e - j * dst.rows; }
-        dst.at(i, j) = src.at(i, idx[j]);
+        const int64_t s = idx[j];
+        // an index outside the source (the reference would panic on it) must not become a wild address: zero + health bit 32
+        if ((uint64_t)s < (uint64_t)src.cols) {
+            dst.at(i, j) = src.at(i, s);
+        } else {
+            dst.at(i, j) = (T)0;
+            if (i == 0) atomicOr(health, 32);
+        }
     }
 }
 template <typename T>
@@ -186,7 +193,7 @@ void gather_cols(rc_context *c, Mat<T> src, const int64_t *idx, Mat<T> dst) {
     RC_REQUIRE(src.rows == dst.rows, RC_INVALID_ARGUMENT, "gather_cols: row mismatch");
     if (dst.empty()) return;
     int grid = (int)std::min<int64_t>(cdiv(dst.rows * dst.cols, 256), 8192);
-    hipLaunchKernelGGL(k_gather_cols<T>, dim3(grid), dim3(256), 0, c->stream, src, idx, dst);
+    hipLaunchKernelGGL(k_gather_cols<T>, dim3(grid), dim3(256), 0, c->stream, src, idx, dst, c->health_word());
 }
 
 // inverse[perm[i]] = i   /root/reference/src/permutation.rs:28-38
@@ -198,6 +205,9 @@ __global__ __launch_bounds__(256) void k_invert_perm(const int64_t *perm, int64_
 }
 void invert_perm(rc_context *c, const int64_t *perm, int64_t n, int64_t *inv) {
     if (n <= 0) return;
+    // every entry starts at -1: an input that is not a permutation leaves -1 behind, which the gathers reject (health bit 32)
+    // instead of following whatever the buffer held
+    RC_HIP(hipMemsetAsync(inv, 0xff, (size_t)n * sizeof(int64_t), c->stream));
     int grid = (int)std::min<int64_t>(cdiv(n, 256), 4096);
     hipLaunchKernelGGL(k_invert_perm, dim3(grid), dim3(256), 0, c->stream, perm, n, inv);
 }

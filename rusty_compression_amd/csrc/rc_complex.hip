@@ -107,17 +107,23 @@ void c_fill(rc_context *c, CV<R> dst, bool identity) {
     hipLaunchKernelGGL(k_c_fill<R>, dim3((unsigned)std::min<int64_t>(cdivi(dst.rows * dst.cols, 256), 8192)), dim3(256), 0, c->stream, dst, identity ? 1 : 0);
 }
 template <typename R>
-__global__ __launch_bounds__(256) void k_c_gather_cols(CV<R> src, const int64_t *idx, CV<R> dst) {  // dst[:, j] = src[:, idx[j]]
+__global__ __launch_bounds__(256) void k_c_gather_cols(CV<R> src, const int64_t *idx, CV<R> dst, int *health) {  // dst[:, j] = src[:, idx[j]]
     const int64_t total = dst.rows * dst.cols;
     for (int64_t e = blockIdx.x * (int64_t)256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
         const int64_t j = e / dst.rows, i = e - j * dst.rows;
-        dst.at(i, j) = src.at(i, idx[j]);
+        const int64_t s = idx[j];
+        if ((uint64_t)s < (uint64_t)src.cols) {
+            dst.at(i, j) = src.at(i, s);
+        } else {  // (as k_gather_cols: no wild addresses; health bit 32)
+            dst.at(i, j) = cplx<R>{0, 0};
+            if (i == 0) atomicOr(health, 32);
+        }
     }
 }
 template <typename R>
 void c_gather_cols(rc_context *c, CV<R> src, const int64_t *idx, CV<R> dst) {
     if (dst.empty()) return;
-    hipLaunchKernelGGL(k_c_gather_cols<R>, dim3((unsigned)std::min<int64_t>(cdivi(dst.rows * dst.cols, 256), 8192)), dim3(256), 0, c->stream, src, idx, dst);
+    hipLaunchKernelGGL(k_c_gather_cols<R>, dim3((unsigned)std::min<int64_t>(cdivi(dst.rows * dst.cols, 256), 8192)), dim3(256), 0, c->stream, src, idx, dst, c->health_word());
 }
 template <typename R>
 __global__ __launch_bounds__(256) void k_c_scale_rows(const R *s, CV<R> m) {  // m[i, :] *= s[i]

@@ -1071,6 +1071,25 @@ def test_cooperative_panel_gives_way_when_the_candidates_do_not_fit(dtype):
     assert is_permutation(ind, n) and rel(q @ r, u[:, ind]) <= (1e-13 if dtype == np.float64 else 1e-5)
 
 
+def test_batch_of_eight_gaussian_matrices_repeats_exactly_under_concurrency():
+    """Eight cooperative panels of different matrices in flight (six admitted by the budget, two waiting at the gate): every
+    permutation stays a permutation and every factor equals the one-matrix call's, round after round.  (A workgroup that had
+    finished its last step used to write its part of the permutation while workgroup 0 was still reading the old occupant of
+    that position: one duplicated column, only under this kind of load.)"""
+    from rusty_compression_amd import batch
+
+    mats = [rc.random_gaussian((4096, 4096), rc.Rng(500 + i), torch.float32) for i in range(8)]
+    want = [batch.column_id_rank(a, 64) for a in mats]
+    for _ in range(25):
+        out = batch.batch_column_id(mats, 64)
+        for (c, z, ind), (c1, z1, i1) in zip(out, want):
+            assert torch.equal(ind, i1), "permutation differs from the one-matrix call"
+            assert torch.equal(c, c1) and torch.equal(z, z1)
+    assert sorted(npy(want[0][2]).tolist()) == list(range(4096))
+    from rusty_compression_amd import _lib
+    assert _lib.default_context().get_health() == 0
+
+
 def test_rccl_self_gather_of_the_packed_factors():
     """rc_comm_* on one GPU (world 1): the packed buffer of a small batch goes through the library's RCCL gather unchanged.
     (The multi-rank layout logic is covered on the CPU: tests/test_dist_cpu.py.)"""
