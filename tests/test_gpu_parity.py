@@ -59,6 +59,39 @@ def test_gemm_all_layouts_and_ragged_shapes(dtype, tol):
     assert rel(npy(rc.conj_matmat(big, y)), big.T.astype(np.float64) @ y) <= tol
 
 
+@pytest.mark.parametrize("opt", ["default", "two_workgroups"])
+def test_f64_gemm_hand_ordered_loops_on_their_shapes(opt):
+    """k_gemm_f64a (hand-ordered main loop, direct-to-LDS copies, masked tail copy): the shapes that reach its instantiations --
+    129..136 rows over a K-contiguous wide operand (the sketch as the transposed problem) and <= 128 rows over an N-contiguous
+    one (the projection) -- around their preconditions: row counts that clamp, one K tile, K tiles that split, wide / narrow N,
+    plus neighbours that must fall back to the compiler-scheduled kernels (K not a multiple of 16, N not a multiple of the tile)."""
+    import os
+    import subprocess
+    import sys
+
+    if opt == "two_workgroups" and os.environ.get("RC_GEMM_SKETCH_2WG") != "1":
+        # the knob is read once per process: run this parametrization in a child with it set
+        env = dict(os.environ, RC_GEMM_SKETCH_2WG="1")
+        res = subprocess.run([sys.executable, "-m", "pytest", __file__, "-m", "gpu", "-q", "-x", "-k", "hand_ordered_loops and two_workgroups"], env=env, capture_output=True, text=True, timeout=600)
+        assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-1000:]
+        return
+    rng = np.random.default_rng(5)
+    for m in (129, 133, 136, 128, 97, 130):
+        for n in (256, 512, 768, 2048, 300):
+            for k in (16, 48, 1024, 2080, 40):
+                a = rng.standard_normal((m, k))
+                b = rng.standard_normal((k, n))
+                ref = a @ b
+                # sketch layout: A stored (k x m) with even leading dimension (M-contiguous), B stored (n x k) (K-contiguous)
+                ta = torch.zeros((k, m + (m & 1)), dtype=torch.float64, device="cuda")[:, :m]
+                ta.copy_(torch.from_numpy(np.ascontiguousarray(a.T)))
+                tb = torch.from_numpy(np.ascontiguousarray(b.T)).cuda()
+                assert rel(npy(rc.dot(ta.t(), tb.t())), ref) <= 1e-13, ("sketch layout", m, n, k)
+                # projection layout: A M-contiguous as above, B stored (k x n) (N-contiguous)
+                tb2 = torch.from_numpy(b).cuda()
+                assert rel(npy(rc.dot(ta.t(), tb2)), ref) <= 1e-13, ("projection layout", m, n, k)
+
+
 def test_gemm_is_deterministic_under_split_k():
     a = rc.random_gaussian((512, 8192), rc.Rng(1))
     b = rc.random_gaussian((8192, 69), rc.Rng(2))
