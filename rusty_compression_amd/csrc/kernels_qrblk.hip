@@ -1061,6 +1061,26 @@ __global__ __launch_bounds__(512, WPE) void k_qrb_coop(QrbCoopArgs<T> a) {
         for (int k2 = 0; k2 < 6; ++k2) g_qrc_dbg[k2] = tph[k2];
 #endif
 
+    // ---- commit: nothing has been written yet; the write-back below must happen in EVERY workgroup or in none.  A workgroup
+    // that gave up inside the loop never arrives here un-aborted, so the counter reaches G only if all of them completed every
+    // step; anybody who does not see that within the spin bound aborts (and then nobody can have seen G either). ------------------
+    if (!aborted) {
+        __syncthreads();
+        if (tid == 0) {
+            unsigned *commit = a.sync + 2;
+            __hip_atomic_fetch_add(commit, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            bool ok = false;
+            for (int it = 0; it <= kSpin; ++it) {
+                if (__hip_atomic_load(commit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)G) { ok = true; break; }
+                if ((it & 31) == 31 && __hip_atomic_load(abortw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) break;
+                __builtin_amdgcn_s_sleep(1);
+            }
+            if (!ok) __hip_atomic_store(abortw, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            sh_exit = ok ? 0 : 1;
+        }
+        __syncthreads();
+        if (sh_exit) aborted = true;
+    }
     // ---- the panel is done: columns, norms and the permutation go back -------------------------------------------------------
     if (!aborted) {
         if (have) {

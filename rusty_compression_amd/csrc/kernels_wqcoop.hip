@@ -67,6 +67,7 @@ __global__ void k_coop_gate(unsigned *sem, unsigned need, unsigned budget, unsig
     for (int i = threadIdx.x; i < hdr_words; i += blockDim.x) __hip_atomic_store(hdr + i, 0ull, __ATOMIC_RELAXED, RC_AGENT);
     if (threadIdx.x != 0) return;
     st_agent(sync + 0, 0u);
+    st_agent(sync + 2, 0u);  // (k_qrb_coop's commit counter)
     unsigned ab = 2u;
     for (int it = 0; it < kSpinLimit; ++it) {
         const unsigned old = __hip_atomic_fetch_add(sem, need, __ATOMIC_RELAXED, RC_AGENT);
