@@ -621,7 +621,7 @@ static void launch_cfg(rc_context *c, GemmArgs<T> g, int target_wgs = 0, int min
 }
 
 template <int ALAY, int BLAY, int BM, int BN, int BK, int WM, int WN, int VEC, int ORIENT, int GLDS = 0>
-static void launch_f64q(rc_context *c, GemmArgs<double> g, int target_wgs = 0) {
+static void launch_f64q(rc_context *c, GemmArgs<double> g, int target_wgs = 0, int min_ksteps = 0) {
     typedef double T;
     constexpr int NT = WM * WN * 64;
     typedef TileStager<T, ALAY, BM, BK, NT, VEC> StA;
@@ -639,7 +639,7 @@ static void launch_f64q(rc_context *c, GemmArgs<double> g, int target_wgs = 0) {
     const int target = tiles >= 8 ? (c->opt_lanes >= 8 && tiles >= 32 ? 1 : (target_wgs > 0 ? target_wgs : target_big)) : target_small;
     int splits = 1;
     const int64_t ksteps = cdiv(g.K, BK);
-    while (tiles * splits < target && splits < 128 && ksteps / (splits * 2) >= (tiles >= 32 ? 16 : 4)) splits *= 2;
+    while (tiles * splits < target && splits < 128 && ksteps / (splits * 2) >= (min_ksteps > 0 ? min_ksteps : (tiles >= 32 ? 16 : 4))) splits *= 2;
     g.kchunk = cdiv(cdiv(g.K, splits), BK) * BK;
     splits = (int)cdiv(g.K, g.kchunk);
     if (splits < 1) splits = 1;
@@ -681,7 +681,7 @@ static bool launch_shape_f64q(rc_context *c, const GemmArgs<double> &g) {
     // Skinny shapes: the narrow dimension is padded to the micro-tile granularity only -- 16 along the
     // "shared" operand's side, 4 along the other (ORIENT picks which) -- so N = 133 costs 136, M = 128 costs 128.
     // (N = 133 through ORIENT 1 / BN = 136 measured slower than BN = 144: 34 B-fragment reads per sub-step.)
-    static const int vn = env_int("RC_GEMM_F64Q_N", 3), vm = env_int("RC_GEMM_F64Q_M", 3), smallk = env_int("RC_GEMM_SMALLK", 1), two_wg = env_int("RC_GEMM_SKETCH_2WG", 0);
+    static const int vn = env_int("RC_GEMM_F64Q_N", 3), vm = env_int("RC_GEMM_F64Q_M", 3), smallk = env_int("RC_GEMM_SMALLK", 1), two_wg = env_int("RC_GEMM_SKETCH_2WG", 0), m32 = env_int("RC_GEMM_F64_M32", 1);
     if (g.M <= 144 && g.N <= 144 && g.M > 80 && g.N > 80) launch_f64q<ALAY, BLAY, 144, 144, 16, 3, 3, VEC, 0>(c, g);
     else if (g.N <= 80) launch_f64q<ALAY, BLAY, 256, 80, 16, 8, 1, VEC, 0>(c, g);
     else if (g.N <= 128 && vn == 3) launch_f64q<ALAY, BLAY, 256, 128, 16, 8, 1, VEC, 0>(c, g);
@@ -689,6 +689,11 @@ static bool launch_shape_f64q(rc_context *c, const GemmArgs<double> &g) {
         if (vn == 1) launch_f64q<ALAY, BLAY, 128, 144, 16, 8, 1, VEC, 0>(c, g);
         else if (vn == 2) launch_f64q<ALAY, BLAY, 128, 144, 16, 4, 1, VEC, 0>(c, g);
         else launch_f64q<ALAY, BLAY, 256, 144, 16, 8, 1, VEC, 0>(c, g);
+    }
+    else if (g.M <= 32 && g.K >= 512 && m32) {
+        // the HBM-bound 32-row products of the blocked QRCP's panel ends (Y = V^T A, V^T Q): 32-row tiles instead of 80 and many
+        // short workgroups, as for f32 (launch_shape)
+        launch_f64q<ALAY, BLAY, 32, 256, 16, 1, 8, VEC, 1>(c, g, 512, 4);
     }
     else if (g.M <= 80) launch_f64q<ALAY, BLAY, 80, 256, 16, 1, 8, VEC, 1>(c, g);
     else if (g.M <= 136 && g.K <= 160 && smallk && g.N >= 2048) {
