@@ -378,8 +378,9 @@ const char *rc_comm_last_error_message(const rc_comm *comm);
  * and norms are real (float / double arguments below), R has a real diagonal (?geqp3), permutation indices as before.
  * rc_gemm_*: trans = 0 none, 1 transpose, 2 conjugate transpose.  rc_random_gaussian_*: element (i, j) takes normals
  * 2 (offset + i cols + j) (real part) and the next one (imaginary part) of the Philox stream, the order the reference
- * draws them in (src/random_matrix.rs:136-143).  Not instantiated for complex: the fused rc_rsvd_id_* / rc_batch_* calls
- * of the measured real hot path; rc_svd_rank_by_tolerance_* (singular values are real: use the f32 / f64 call). */
+ * draws them in (src/random_matrix.rs:136-143).  rc_rsvd_id_c* / rc_batch_column_id_c* are compositions of the calls below with
+ * the real entry points' members, layout and "null = skipped" rule (B = Q^H A formed once; not the tuned real hot path);
+ * rc_svd_rank_by_tolerance_c* forwards to the real call (singular values are real). */
 typedef struct rc_complex32 { float re, im; } rc_complex32;
 typedef struct rc_complex64 { double re, im; } rc_complex64;
 rc_status rc_random_gaussian_c64(rc_context *ctx, rc_matrix out, uint64_t seed, uint64_t offset);
@@ -408,6 +409,9 @@ rc_status rc_sample_range_by_rank_c64(rc_context *ctx, rc_matrix a, int64_t k, i
 rc_status rc_sample_range_power_iteration_c64(rc_context *ctx, rc_matrix a, int64_t k, int64_t p, int64_t it_count, rc_matrix omega, uint64_t seed, rc_matrix q);
 rc_status rc_sample_range_adaptive_c64(rc_context *ctx, rc_matrix a, double rel_tol, int64_t sample_size, rc_matrix omegas, uint64_t seed, rc_matrix q_cap, int64_t *rank, int64_t *hist_rank, double *hist_res, int64_t hist_cap, int64_t *hist_len);
 rc_status rc_column_id_rank_c64(rc_context *ctx, rc_matrix a, int64_t k, rc_matrix c, rc_matrix z, int64_t *col_ind);
+rc_status rc_svd_rank_by_tolerance_c64(rc_context *ctx, const double *s, int64_t len, double tol, int64_t *rank);
+rc_status rc_rsvd_id_c64(rc_context *ctx, rc_matrix a, int64_t k, int64_t p, rc_matrix omega, uint64_t seed, const rc_rsvd_id_out *out);
+rc_status rc_batch_column_id_c64(rc_context *const *ctxs, int32_t nctx, const rc_matrix *mats, int32_t count, int64_t k, void *packed);
 rc_status rc_random_gaussian_c32(rc_context *ctx, rc_matrix out, uint64_t seed, uint64_t offset);
 rc_status rc_matmat_c32(rc_context *ctx, rc_matrix a, rc_matrix x, rc_matrix y);
 rc_status rc_conj_matmat_c32(rc_context *ctx, rc_matrix a, rc_matrix x, rc_matrix y);
@@ -434,6 +438,9 @@ rc_status rc_sample_range_by_rank_c32(rc_context *ctx, rc_matrix a, int64_t k, i
 rc_status rc_sample_range_power_iteration_c32(rc_context *ctx, rc_matrix a, int64_t k, int64_t p, int64_t it_count, rc_matrix omega, uint64_t seed, rc_matrix q);
 rc_status rc_sample_range_adaptive_c32(rc_context *ctx, rc_matrix a, double rel_tol, int64_t sample_size, rc_matrix omegas, uint64_t seed, rc_matrix q_cap, int64_t *rank, int64_t *hist_rank, double *hist_res, int64_t hist_cap, int64_t *hist_len);
 rc_status rc_column_id_rank_c32(rc_context *ctx, rc_matrix a, int64_t k, rc_matrix c, rc_matrix z, int64_t *col_ind);
+rc_status rc_svd_rank_by_tolerance_c32(rc_context *ctx, const float *s, int64_t len, double tol, int64_t *rank);
+rc_status rc_rsvd_id_c32(rc_context *ctx, rc_matrix a, int64_t k, int64_t p, rc_matrix omega, uint64_t seed, const rc_rsvd_id_out *out);
+rc_status rc_batch_column_id_c32(rc_context *const *ctxs, int32_t nctx, const rc_matrix *mats, int32_t count, int64_t k, void *packed);
 
 #ifdef __cplusplus
 }

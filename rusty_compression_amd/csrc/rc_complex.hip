@@ -846,6 +846,71 @@ void c_apply_perm(rc_context *c, int mode, CV<R> in, const int64_t *perm, int64_
     else c_gather_cols(c, in.t(), idx, out.t());
 }
 
+static rc_status c_svd_rank_fwd(rc_context *ctx, const double *s, int64_t len, double tol, int64_t *rank) { return rc_svd_rank_by_tolerance_f64(ctx, s, len, tol, rank); }
+static rc_status c_svd_rank_fwd(rc_context *ctx, const float *s, int64_t len, double tol, int64_t *rank) { return rc_svd_rank_by_tolerance_f32(ctx, s, len, tol, rank); }
+
+// the cfg3 pipeline for complex scalars (call sequence of rsvd_id in rc_api.hip): range -> B = Q^H A once -> SVD(B), QRCP(B), column ID
+template <typename R>
+void c_rsvd_id(rc_context *c, CV<R> a, int64_t k, int64_t p, CV<R> omega, uint64_t seed, const rc_rsvd_id_out &o) {
+    const int64_t m = a.rows, n = a.cols;
+    RC_REQUIRE(k >= 1 && k + p <= m && k <= n, RC_INVALID_ARGUMENT, "rsvd_id: need 1 <= k, k + p <= m, k <= n");
+    ArenaMark mark(c);
+    CV<R> range = view_of<R>(o.range_q);
+    if (range.p == nullptr) range = tmp_cm<R>(c, m, k);
+    RC_REQUIRE(range.rows == m && range.cols == k, RC_INVALID_ARGUMENT, "rsvd_id: range_q must be m x k");
+    c_sample_range_by_rank<R>(c, a, k, p, omega, seed, range);
+    CV<R> b = tmp_cm<R>(c, k, n);
+    c_gemm<R>(c, 2, 0, one<R>(), range, a, zero<R>(), b);
+    const bool want_id = o.id_c.data || o.id_z.data || o.qr_q.data || o.qr_r.data || o.qr_ind;
+    const bool want_svd = o.u.data || o.s || o.vt.data;
+    if (want_svd) RC_REQUIRE(o.u.data && o.s && o.vt.data, RC_INVALID_ARGUMENT, "rsvd_id: u, s, vt must be given together");
+    if (want_id) {
+        CV<R> qb = tmp_cm<R>(c, k, k);
+        CV<R> r = o.qr_r.data ? view_of<R>(o.qr_r) : tmp_cm<R>(c, k, n);
+        int64_t *ind = o.qr_ind ? o.qr_ind : c->alloc<int64_t>((size_t)n);
+        c_pivoted_qr<R>(c, b, qb, r, ind, k);  // works on its own copy of b
+        CV<R> q = o.qr_q.data ? view_of<R>(o.qr_q) : tmp_cm<R>(c, m, k);
+        c_gemm<R>(c, 0, 0, one<R>(), range, qb, zero<R>(), q);
+        if (o.id_c.data || o.id_z.data) {
+            RC_REQUIRE(o.id_c.data && o.id_z.data, RC_INVALID_ARGUMENT, "rsvd_id: id_c and id_z must be given together");
+            c_qr_column_id<R>(c, q, r, ind, view_of<R>(o.id_c), view_of<R>(o.id_z));
+        }
+    }
+    if (want_svd) {
+        CV<R> ub = tmp_cm<R>(c, k, k);
+        c_compute_svd<R>(c, b, ub, static_cast<R *>(o.s), view_of<R>(o.vt));
+        c_gemm<R>(c, 0, 0, one<R>(), range, ub, zero<R>(), view_of<R>(o.u));
+    }
+}
+
+// rank-k column IDs of `count` same-shaped complex matrices into the packed buffer (layout of rc_batch_packed_bytes with
+// elem_size = sizeof(complex)); matrix i runs on context i % nctx, every context is waited for at the end
+template <typename R>
+void c_batch_column_id(rc_context *const *ctxs, int nctx, const rc_matrix *mats, int count, int64_t k, void *packed) {
+    RC_REQUIRE(count >= 0 && k >= 1, RC_INVALID_ARGUMENT, "batch_column_id: k >= 1");
+    if (count == 0) return;
+    RC_REQUIRE(mats != nullptr && packed != nullptr, RC_INVALID_ARGUMENT, "batch_column_id: null argument");
+    const int64_t m = mats[0].rows, n = mats[0].cols;
+    RC_REQUIRE(k <= std::min(m, n), RC_INVALID_ARGUMENT, "batch_column_id: rank exceeds min(m, n)");
+    const size_t per = rc_batch_packed_bytes(m, n, k, (int32_t)sizeof(cplx<R>));
+    for (int i = 0; i < count; ++i) {
+        RC_REQUIRE(mats[i].rows == m && mats[i].cols == n && mats[i].data, RC_INVALID_ARGUMENT, "batch_column_id: all matrices must have the shape of the first");
+        rc_context *c = ctxs[i % nctx];
+        RC_REQUIRE(c != nullptr, RC_INVALID_ARGUMENT, "batch_column_id: bad context");
+        char *base = static_cast<char *>(packed) + (size_t)i * per;
+        cplx<R> *cz = reinterpret_cast<cplx<R> *>(base);
+        int64_t *ind = reinterpret_cast<int64_t *>(base + per - (size_t)n * sizeof(int64_t));
+        CV<R> A = view_of<R>(mats[i]);
+        CV<R> cm{cz, m, k, k, 1}, z{cz + (size_t)m * k, k, n, n, 1};
+        c->reset_arena();
+        ArenaMark mark(c);
+        CV<R> q = tmp_cm<R>(c, m, k), r = tmp_cm<R>(c, k, n);
+        c_pivoted_qr<R>(c, A, q, r, ind, k);
+        c_qr_column_id<R>(c, q, r, ind, cm, z);
+    }
+    for (int l = 0; l < std::min(nctx, count); ++l) RC_HIP(hipStreamSynchronize(ctxs[l]->stream));
+}
+
 }  // namespace
 
 // ================================================================================================ extern "C"
@@ -1018,6 +1083,20 @@ extern "C" {
             c_pivoted_qr<R>(ctx, A, q, r, col_ind, kk);                                                                                   \
             c_qr_column_id<R>(ctx, q, r, col_ind, view_of<R>(c), view_of<R>(z));                                                          \
         });                                                                                                                               \
+    }                                                                                                                                     \
+    /* singular values are real for every scalar type (src/svd.rs:86-101) */                                                              \
+    rc_status rc_svd_rank_by_tolerance_##SUF(rc_context *ctx, const R *s, int64_t len, double tol, int64_t *rank) {                        \
+        return c_svd_rank_fwd(ctx, s, len, tol, rank);                                                                                    \
+    }                                                                                                                                     \
+    /* the fused rSVD + ID call (same members, same "null = skipped" rule as rc_rsvd_id_f64); B = Q^H A is formed once */                \
+    rc_status rc_rsvd_id_##SUF(rc_context *ctx, rc_matrix a, int64_t k, int64_t p, rc_matrix omega, uint64_t seed, const rc_rsvd_id_out *out) { \
+        if (!out) return RC_INVALID_ARGUMENT;                                                                                             \
+        return guarded_c(ctx, [&] { c_rsvd_id<R>(ctx, view_of<R>(a), k, p, view_of<R>(omega), seed, *out); });                            \
+    }                                                                                                                                     \
+    /* cfg5's batch for complex matrices: the same packed layout, one rank-k column ID per matrix, round-robin over the contexts */      \
+    rc_status rc_batch_column_id_##SUF(rc_context *const *ctxs, int32_t nctx, const rc_matrix *mats, int32_t count, int64_t k, void *packed) { \
+        if (!ctxs || nctx < 1 || !ctxs[0]) return RC_INVALID_ARGUMENT;                                                                    \
+        return guarded_c(ctxs[0], [&] { c_batch_column_id<R>(ctxs, nctx, mats, count, k, packed); });                                     \
     }
 
 RC_DEFINE_COMPLEX(c64, double, rc_complex64)

@@ -212,3 +212,69 @@ def test_complex_rank_k_column_id_and_error_behaviour():
         rc.QR.compute_from(np.eye(6, dtype=np.complex128)).compress(CT.ADAPTIVE(1e-3))
     with pytest.raises(AssertionError):
         rc.apply_permutation(a, np.arange(3), rc.MatrixPermutationMode.COL)
+
+
+@pytest.mark.parametrize("dtype", [np.complex128, np.complex64])
+def test_complex_fused_rsvd_id_batch_and_rank_by_tolerance(dtype):
+    """rc_rsvd_id_c*, rc_batch_column_id_c*, rc_svd_rank_by_tolerance_c*: the fused call equals the separate complex calls (same
+    Omega), the batch equals the one-matrix calls bit for bit, the rank rule is the real one."""
+    import ctypes
+
+    from rusty_compression_amd import _lib, batch
+
+    t = TOLC[np.dtype(dtype)]
+    suf = _lib.suffix(torch.complex128 if dtype == np.complex128 else torch.complex64)
+    rng = np.random.default_rng(21)
+    m, n, k, p = 260, 180, 20, 5
+    a = torch.from_numpy(o.random_approximate_low_rank_matrix((m, n), 1.0, 1e-8 if dtype == np.complex128 else 1e-4, rng, dtype)).cuda()
+    om = torch.from_numpy(o.random_gaussian((n, k + p), rng, dtype)).cuda()
+    rdt = torch.float64 if dtype == np.complex128 else torch.float32
+    e = lambda r, c: torch.empty((r, c), dtype=a.dtype, device="cuda")
+    rq, u, vt, qq, qr_, c_, z_ = e(m, k), e(m, k), e(k, n), e(m, k), e(k, n), e(m, k), e(k, n)
+    sv = torch.empty(k, dtype=rdt, device="cuda")
+    ind = torch.empty(n, dtype=torch.int64, device="cuda")
+    out = _lib.rc_rsvd_id_out(_lib.mat(rq), _lib.mat(u), ctypes.c_void_p(sv.data_ptr()), _lib.mat(vt), _lib.mat(qq), _lib.mat(qr_),
+                              ctypes.c_void_p(ind.data_ptr()), _lib.mat(c_), _lib.mat(z_))
+    ctx = _lib.default_context()
+    ctx.call(f"rc_rsvd_id_{suf}", _lib.mat(a), ctypes.c_int64(k), ctypes.c_int64(p), _lib.mat(om), ctypes.c_uint64(0), ctypes.byref(out))
+    q1 = rc.sample_range_by_rank(a, k, p, om)
+    svd1 = rc.SVD.compute_from_range_estimate(q1, a)
+    qr1 = rc.QR.compute_from_range_estimate(q1, a)
+    cid1 = qr1.column_id()
+    an = npy(a)
+    assert rel(npy(rq), npy(q1)) <= t["factor"]
+    assert np.abs(npy(sv) - npy(svd1.s)).max() <= t["sval"] * 10 * float(svd1.s[0])
+    assert rel((npy(u) * npy(sv)) @ npy(vt), npy(svd1.to_mat())) <= t["factor"] * 10
+    assert np.array_equal(npy(ind)[:k], npy(qr1.ind)[:k]) and rel(npy(qr_), npy(qr1.r)) <= t["factor"] * 10
+    assert rel(npy(qq) @ npy(qr_), npy(qr1.q) @ npy(qr1.r)) <= t["factor"] * 10
+    assert rel(npy(c_) @ npy(z_), npy(cid1.c) @ npy(cid1.z)) <= t["factor"] * 100
+    assert abs(rel(npy(c_) @ npy(z_), an) - rel(npy(cid1.c) @ npy(cid1.z), an)) <= t["factor"] * 10
+    # rank rule on the (real) singular values
+    rk = ctypes.c_int64(-1)
+    ctx.call(f"rc_svd_rank_by_tolerance_{suf}", ctypes.c_void_p(sv.data_ptr()), ctypes.c_int64(k), ctypes.c_double(0.5), ctypes.byref(rk))
+    rk_real = ctypes.c_int64(-2)
+    ctx.call(f"rc_svd_rank_by_tolerance_{'f64' if dtype == np.complex128 else 'f32'}", ctypes.c_void_p(sv.data_ptr()), ctypes.c_int64(k), ctypes.c_double(0.5), ctypes.byref(rk_real))
+    assert rk.value == rk_real.value and 1 <= rk.value <= k
+    # batch of three complex matrices on two contexts == the one-matrix calls
+    mats = [torch.from_numpy(o.random_approximate_low_rank_matrix((96, 80), 1.0, 1e-6 if dtype == np.complex128 else 1e-3, rng, dtype)).cuda() for _ in range(3)]
+    kk = 12
+    es = mats[0].element_size()
+    per = ((96 * kk + kk * 80) * es + 7) // 8 * 8 + 80 * 8
+    packed = torch.empty(3 * per, dtype=torch.uint8, device="cuda")
+    c2 = _lib.Context(0, None)
+    try:
+        ctxs = (ctypes.c_void_p * 2)(ctx._h, c2._h)
+        marr = (_lib.rc_matrix * 3)(*[_lib.mat(x) for x in mats])
+        fn = getattr(_lib.lib(), f"rc_batch_column_id_{suf}")
+        fn.restype = ctypes.c_int32
+        st = fn(ctxs, ctypes.c_int32(2), marr, ctypes.c_int32(3), ctypes.c_int64(kk), ctypes.c_void_p(packed.data_ptr()))
+        assert st == 0, f"rc_batch_column_id_{suf} returned {st}"
+    finally:
+        c2.close()
+    for i, x in enumerate(mats):
+        blk = packed[i * per:(i + 1) * per]
+        cc = blk[: 96 * kk * es].view(x.dtype).reshape(96, kk)
+        zz = blk[96 * kk * es:(96 * kk + kk * 80) * es].view(x.dtype).reshape(kk, 80)
+        ii = blk[per - 80 * 8:].view(torch.int64)
+        c1, z1, i1 = batch.column_id_rank(x, kk)
+        assert torch.equal(ii, i1) and torch.equal(cc, c1) and torch.equal(zz, z1)
