@@ -368,6 +368,33 @@ rc_status rc_comm_init(rc_comm **comm, int32_t world, int32_t rank, const void *
 rc_status rc_comm_gather(rc_comm *comm, rc_context *ctx, const void *send, void *recv, size_t bytes_per_rank, int32_t root);
 rc_status rc_comm_destroy(rc_comm *comm);
 const char *rc_comm_last_error_message(const rc_comm *comm);
+/* The two collectives of the row-sharded single-matrix path below (all ranks end with the same bits):
+ *   rc_comm_all_gather      recv[r * bytes_per_rank ...] = rank r's send (send may be the rank's own block of recv)
+ *   rc_comm_all_reduce_sum  buf[i] = sum over the ranks, in place; elem_size 8 = double, 4 = float
+ * ordered on the context's stream (ncclAllGather / ncclAllReduce: asynchronous).  rc_comm_world reports the extent. */
+rc_status rc_comm_all_gather(rc_comm *comm, rc_context *ctx, const void *send, void *recv, size_t bytes_per_rank);
+rc_status rc_comm_all_reduce_sum(rc_comm *comm, rc_context *ctx, void *buf, size_t count, int32_t elem_size);
+rc_status rc_comm_world(const rc_comm *comm, int32_t *world, int32_t *rank);
+/* A communicator over the HOST's own communication layer (MPI, gloo, a test harness) instead of RCCL: the library stages
+ * the (small) buffers of the two collectives above through host memory, waits for the stream and calls back.  Both
+ * callbacks work on host pointers, return 0 on success, and must leave the same bytes on every rank.
+ * rc_comm_gather is not available on such a communicator. */
+typedef int32_t (*rc_host_all_gather_fn)(void *user, const void *send, void *recv, size_t bytes_per_rank);
+typedef int32_t (*rc_host_all_reduce_sum_fn)(void *user, void *buf, size_t count, int32_t elem_size);
+rc_status rc_comm_init_host(rc_comm **comm, int32_t world, int32_t rank, int32_t device, rc_host_all_gather_fn all_gather,
+                            rc_host_all_reduce_sum_fn all_reduce_sum, void *user);
+
+/* ----------------------------------------- one matrix sharded by rows over the GPUs -- */
+/* The cfg3 pipeline (sample_range_by_rank -> SVD / QR::compute_from_range_estimate -> column_id, src/random_sampling.rs:103-118,
+ * src/svd.rs:171-183, src/qr.rs:311-323, :270-309) for ONE matrix A = [A_0; ...; A_{W-1}] whose row block a_local
+ * (m_r x n, m_r >= k + p) lives on this rank; the reference is single-process, so there is no file:line for the split.
+ * Local: the sketch Y_r = A_r Omega (Omega = the Philox stream of `seed`, identical on every rank), its pivoted QR, every
+ * product with A.  Exchanged: the l x l factor of every rank (all-gather; the pivoted QR of the stack gives THE pivoted
+ * QR of Y, TSQR) and the k x n projection B (all-reduce).  out: range_q, u, qr_q, id_c have m_r rows (this rank's rows
+ * of the global factors); s, vt, qr_r, qr_ind, id_z are replicated bit-identically.  "NULL = skipped" as in rc_rsvd_id.
+ * comm == NULL: one rank.  Blocking where the transport is (host communicators); not capturable. */
+rc_status rc_rsvd_id_row_sharded_f64(rc_comm *comm, rc_context *ctx, rc_matrix a_local, int64_t k, int64_t p, uint64_t seed, const rc_rsvd_id_out *out);
+rc_status rc_rsvd_id_row_sharded_f32(rc_comm *comm, rc_context *ctx, rc_matrix a_local, int64_t k, int64_t p, uint64_t seed, const rc_rsvd_id_out *out);
 
 /* ------------------------------------------------------------- complex scalars (c32 / c64) -- */
 /* The reference instantiates every trait for f32, f64, c32 and c64 (macros at src/qr.rs:408-416, src/pivoted_qr.rs:187-190,

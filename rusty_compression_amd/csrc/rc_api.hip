@@ -626,6 +626,9 @@ struct Fork {
     }
 };
 
+template <typename T>
+void rsvd_id_consumers(rc_context *c, Mat<T> range, Mat<T> b, const rc_rsvd_id_out &o);
+
 // cfg3 "rSVD + ID" without host synchronisation
 template <typename T>
 void rsvd_id(rc_context *c, Mat<T> a, int64_t k, int64_t p, Mat<T> omega, uint64_t seed, const rc_rsvd_id_out &o) {
@@ -645,6 +648,14 @@ void rsvd_id(rc_context *c, Mat<T> a, int64_t k, int64_t p, Mat<T> omega, uint64
         ProfScope ps(c, "stage:project B=Q^H A");
         project(c, range, a, b);
     }
+    rsvd_id_consumers(c, range, b, o);
+}
+
+// the two consumers of B = range^H A (k x n, destroyed): SVD::compute_from_range_estimate (src/svd.rs:171-183) and
+// QR::compute_from_range_estimate + column_id (src/qr.rs:311-323, :270-309); outputs have range.rows rows
+template <typename T>
+void rsvd_id_consumers(rc_context *c, Mat<T> range, Mat<T> b, const rc_rsvd_id_out &o) {
+    const int64_t m = range.rows, k = b.rows, n = b.cols;
     const bool want_id = o.id_c.data || o.id_z.data || o.qr_q.data || o.qr_r.data || o.qr_ind;
     Mat<T> wq;
     if (want_id) {
@@ -676,6 +687,64 @@ void rsvd_id(rc_context *c, Mat<T> a, int64_t k, int64_t p, Mat<T> omega, uint64
         gemm<T>(c, 1, range, ub, 0, from_c<T>(o.u));
     }
     fork.join();
+}
+
+// One matrix sharded by ROWS over the ranks of `comm` (comm == nullptr: one rank).  This rank holds
+// a (m_r x n, m_r >= k + p).  The sketch, the factorizations of the tall blocks and every product with A stay local; what
+// crosses the links is the l x l factor of every rank (all-gather) and the k x n projection (all-reduce):
+//   Omega            the same Philox stream on every rank, nothing is sent      (src/random_sampling.rs:103-118)
+//   Y_r = A_r Omega, Y_r P_r = Q_r R_r, S_r = R_r P_r^T (l x l)                   local
+//   S = [S_0; ...; S_{W-1}] all-gathered; S P = Q_S R redundantly on every rank  => Y P = blockdiag(Q_r) Q_S R is THE pivoted
+//                    QR of Y: S has the column norms and inner products of Y, so pivots and R are ?geqp3's of the whole Y
+//   range_r = Q_r Q_S[block r, :k];  B = sum_r range_r^H A_r (one all-reduce);  SVD / pivoted QR / ID of B redundantly,
+//   U_r = range_r U_b, Q_r' = range_r Q_b, C_r = Q_r' R11                         local (src/svd.rs:171-183, src/qr.rs:311-323)
+// Row-sharded outputs: range_q, u, qr_q, id_c (m_r rows); replicated, bit-identical on every rank: s, vt, qr_r, qr_ind, id_z.
+template <typename T>
+void rsvd_id_row_sharded(rc_comm *comm, rc_context *c, Mat<T> a, int64_t k, int64_t p, uint64_t seed, const rc_rsvd_id_out &o) {
+    int32_t world = 1, rank = 0;
+    if (comm) RC_REQUIRE(rc_comm_world(comm, &world, &rank) == RC_OK, RC_INVALID_ARGUMENT, "rsvd_id_row_sharded: bad communicator");
+    const int64_t mr = a.rows, n = a.cols, l = k + p;
+    RC_REQUIRE(k >= 1 && p >= 0 && k <= n, RC_INVALID_ARGUMENT, "rsvd_id_row_sharded: need 1 <= k <= n, p >= 0");
+    RC_REQUIRE(l <= mr, RC_INVALID_ARGUMENT, "rsvd_id_row_sharded: every rank needs at least k + p = %lld rows, this one has %lld", (long long)l, (long long)mr);
+    RC_REQUIRE(!c->capturing, RC_INVALID_ARGUMENT, "rsvd_id_row_sharded: not capturable (the collectives may be staged through the host)");
+    auto comm_ok = [&](rc_status st, const char *what) {
+        if (st != RC_OK) fail(st, "rsvd_id_row_sharded: %s failed: %s", what, rc_comm_last_error_message(comm));
+    };
+    ArenaMark mark(c);
+    Mat<T> range = from_c<T>(o.range_q);
+    if (range.p == nullptr) range = tmp_colmajor<T>(c, mr, k);
+    RC_REQUIRE(range.rows == mr && range.cols == k, RC_INVALID_ARGUMENT, "rsvd_id_row_sharded: range_q must be m_r x k");
+    {
+        ProfScope ps(c, "stage:sharded range (local sketch + QR, all-gather of the l x l factors)");
+        ArenaMark inner(c);
+        Mat<T> omega = tmp_rowmajor<T>(c, n, l);
+        fill_gaussian(c, omega, seed, 0);
+        Mat<T> y = tmp_colmajor<T>(c, mr, l);
+        gemm<T>(c, 1, a, omega, 0, y);
+        Mat<T> qr = tmp_colmajor<T>(c, mr, l), rr = tmp_rowmajor<T>(c, l, l);
+        int64_t *ind = c->alloc<int64_t>((size_t)l), *inv = c->alloc<int64_t>((size_t)l);
+        qrcp_core(c, y, l, true, qr, rr, ind);
+        invert_perm(c, ind, l, inv);
+        const size_t blk = (size_t)l * (size_t)rr.rs;  // one rank's factor incl. the row padding of the temporaries
+        Mat<T> sall = rowmajor(c->alloc<T>(blk * (size_t)world), (int64_t)world * l, l, rr.rs);
+        Mat<T> sr = sall.sub((int64_t)rank * l, l, 0, l);
+        RC_HIP(hipMemsetAsync(sr.p, 0, blk * sizeof(T), c->stream));
+        gather_cols(c, rr, inv, sr);  // S_r = R_r P_r^T
+        if (comm) comm_ok(rc_comm_all_gather(comm, c, sr.p, sall.p, blk * sizeof(T)), "all-gather");
+        Mat<T> ws = tmp_colmajor<T>(c, sall.rows, l), qs = tmp_colmajor<T>(c, sall.rows, k);
+        copy_mat(c, sall, ws);
+        int64_t *ind2 = c->alloc<int64_t>((size_t)l);
+        qrcp_core(c, ws, k, true, qs, Mat<T>(), ind2);  // only the first k steps influence Q_S[:, :k]
+        gemm<T>(c, 1, qr, qs.sub((int64_t)rank * l, l, 0, k), 0, range);
+    }
+    Mat<T> b = tmp_rowmajor<T>(c, k, n);
+    {
+        ProfScope ps(c, "stage:sharded project B = sum_r range_r^H A_r (all-reduce)");
+        if (b.rs != n) RC_HIP(hipMemsetAsync(b.p, 0, (size_t)k * (size_t)b.rs * sizeof(T), c->stream));
+        project(c, range, a, b);
+        if (comm) comm_ok(rc_comm_all_reduce_sum(comm, c, b.p, (size_t)k * (size_t)b.rs, (int32_t)sizeof(T)), "all-reduce");
+    }
+    rsvd_id_consumers(c, range, b, o);
 }
 
 // cfg5 unit: rank-k column ID of a dense matrix through the truncated factorization
@@ -1143,6 +1212,13 @@ rc_status rc_invert_permutation(rc_context *ctx, const int64_t *perm, int64_t n,
         return guarded(ctx, [&] {                                                                                                        \
             RC_REQUIRE(out != nullptr, RC_INVALID_ARGUMENT, "rsvd_id: null output descriptor");                                          \
             rsvd_id<T>(ctx, from_c<T>(a), k, p, from_c<T>(omega), seed, *out);                                                           \
+        });                                                                                                                              \
+    }                                                                                                                                    \
+    rc_status rc_rsvd_id_row_sharded_##SUF(rc_comm *comm, rc_context *ctx, rc_matrix a_local, int64_t k, int64_t p, uint64_t seed,       \
+                                           const rc_rsvd_id_out *out) {                                                                  \
+        return guarded(ctx, [&] {                                                                                                        \
+            RC_REQUIRE(out != nullptr, RC_INVALID_ARGUMENT, "rsvd_id_row_sharded: null output descriptor");                              \
+            rsvd_id_row_sharded<T>(comm, ctx, from_c<T>(a_local), k, p, seed, *out);                                                     \
         });                                                                                                                              \
     }                                                                                                                                    \
     rc_status rc_column_id_rank_##SUF(rc_context *ctx, rc_matrix a, int64_t k, rc_matrix c, rc_matrix z, int64_t *col_ind) {             \

@@ -21,6 +21,7 @@
 #include <algorithm>
 #include <mutex>
 #include <thread>
+#include <vector>
 
 using namespace rc;
 
@@ -201,6 +202,8 @@ struct Rccl {
     ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
     ncclResult_t (*Send)(const void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*Recv)(void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*AllGather)(const void *, void *, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*AllReduce)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*GroupStart)() = nullptr;
     ncclResult_t (*GroupEnd)() = nullptr;
     const char *(*GetErrorString)(ncclResult_t) = nullptr;
@@ -222,6 +225,8 @@ Rccl *rccl() {
         r.CommDestroy = reinterpret_cast<decltype(r.CommDestroy)>(sym("ncclCommDestroy"));
         r.Send = reinterpret_cast<decltype(r.Send)>(sym("ncclSend"));
         r.Recv = reinterpret_cast<decltype(r.Recv)>(sym("ncclRecv"));
+        r.AllGather = reinterpret_cast<decltype(r.AllGather)>(sym("ncclAllGather"));
+        r.AllReduce = reinterpret_cast<decltype(r.AllReduce)>(sym("ncclAllReduce"));
         r.GroupStart = reinterpret_cast<decltype(r.GroupStart)>(sym("ncclGroupStart"));
         r.GroupEnd = reinterpret_cast<decltype(r.GroupEnd)>(sym("ncclGroupEnd"));
         r.GetErrorString = reinterpret_cast<decltype(r.GetErrorString)>(sym("ncclGetErrorString"));
@@ -232,7 +237,11 @@ Rccl *rccl() {
 }  // namespace
 
 struct rc_comm {
-    ncclComm_t comm = nullptr;
+    ncclComm_t comm = nullptr;  // RCCL transport (rc_comm_init), or
+    rc_host_all_gather_fn host_gather = nullptr;  // the host's own collectives (rc_comm_init_host): buffers staged through the host
+    rc_host_all_reduce_sum_fn host_reduce = nullptr;
+    void *user = nullptr;
+    std::vector<char> stage_in, stage_out;
     int world = 1, rank = 0, device = 0;
     std::string last_error;
 };
@@ -299,6 +308,11 @@ rc_status rc_comm_gather(rc_comm *comm, rc_context *ctx, const void *send, void 
     if (!comm || !ctx || root < 0 || root >= comm->world) return RC_INVALID_ARGUMENT;
     if (bytes_per_rank == 0) return RC_OK;
     if (!send || (comm->rank == root && !recv)) return RC_INVALID_ARGUMENT;
+    if (!comm->comm) {  // host transport: the gather is the all-gather's block on the root
+        comm->last_error = "rc_comm_gather needs the RCCL transport (use rc_comm_all_gather with a host communicator)";
+        ctx->last_error = comm->last_error;
+        return RC_INVALID_ARGUMENT;
+    }
     Rccl *r = rccl();
     DeviceGuardB dg(comm->device);
     auto chk = [&](ncclResult_t e) {
@@ -314,6 +328,95 @@ rc_status rc_comm_gather(rc_comm *comm, rc_context *ctx, const void *send, void 
     if (ok) ok = chk(r->Send(send, bytes_per_rank, ncclUint8, root, comm->comm, ctx->stream));
     const bool ended = chk(r->GroupEnd());
     return ok && ended ? RC_OK : RC_RUNTIME_ERROR;
+}
+
+rc_status rc_comm_init_host(rc_comm **comm, int32_t world, int32_t rank, int32_t device, rc_host_all_gather_fn all_gather,
+                            rc_host_all_reduce_sum_fn all_reduce_sum, void *user) {
+    if (!comm) return RC_INVALID_ARGUMENT;
+    *comm = nullptr;
+    if (world < 1 || rank < 0 || rank >= world || !all_gather || !all_reduce_sum) return RC_INVALID_ARGUMENT;
+    rc_comm *c = new rc_comm();
+    c->world = world; c->rank = rank; c->device = device;
+    c->host_gather = all_gather; c->host_reduce = all_reduce_sum; c->user = user;
+    *comm = c;
+    return RC_OK;
+}
+
+rc_status rc_comm_world(const rc_comm *comm, int32_t *world, int32_t *rank) {
+    if (!comm) return RC_INVALID_ARGUMENT;
+    if (world) *world = comm->world;
+    if (rank) *rank = comm->rank;
+    return RC_OK;
+}
+
+namespace {
+bool comm_fail(rc_comm *comm, rc_context *ctx, const std::string &msg) {
+    comm->last_error = msg;
+    ctx->last_error = msg;
+    return false;
+}
+bool comm_hip(rc_comm *comm, rc_context *ctx, hipError_t e, const char *what) {
+    return e == hipSuccess ? true : comm_fail(comm, ctx, std::string(what) + ": " + hipGetErrorString(e));
+}
+}  // namespace
+
+// recv[r * bytes_per_rank ...] = rank r's `send`, on every rank, ordered on the context's stream.  `send` may be the
+// rank's own block inside `recv` (in place).  RCCL transport: asynchronous (ncclAllGather); host transport: the stream is
+// waited for, the host's callback runs on host copies, the result is copied back before the call returns.
+rc_status rc_comm_all_gather(rc_comm *comm, rc_context *ctx, const void *send, void *recv, size_t bytes_per_rank) {
+    if (!comm || !ctx) return RC_INVALID_ARGUMENT;
+    if (bytes_per_rank == 0) return RC_OK;
+    if (!send || !recv) return RC_INVALID_ARGUMENT;
+    DeviceGuardB dg(comm->device);
+    char *own = static_cast<char *>(recv) + (size_t)comm->rank * bytes_per_rank;
+    if (comm->world == 1 && !comm->comm) {  // (an RCCL communicator of one rank still goes through ncclAllGather)
+        if (own != send && !comm_hip(comm, ctx, hipMemcpyAsync(own, send, bytes_per_rank, hipMemcpyDeviceToDevice, ctx->stream), "all_gather copy")) return RC_RUNTIME_ERROR;
+        return RC_OK;
+    }
+    if (comm->host_gather) {
+        comm->stage_in.resize(bytes_per_rank);
+        comm->stage_out.resize(bytes_per_rank * (size_t)comm->world);
+        if (!comm_hip(comm, ctx, hipMemcpyAsync(comm->stage_in.data(), send, bytes_per_rank, hipMemcpyDeviceToHost, ctx->stream), "all_gather D2H")) return RC_RUNTIME_ERROR;
+        if (!comm_hip(comm, ctx, hipStreamSynchronize(ctx->stream), "all_gather wait")) return RC_RUNTIME_ERROR;
+        if (comm->host_gather(comm->user, comm->stage_in.data(), comm->stage_out.data(), bytes_per_rank) != 0) {
+            comm_fail(comm, ctx, "the host's all_gather callback reported an error");
+            return RC_RUNTIME_ERROR;
+        }
+        if (!comm_hip(comm, ctx, hipMemcpyAsync(recv, comm->stage_out.data(), comm->stage_out.size(), hipMemcpyHostToDevice, ctx->stream), "all_gather H2D")) return RC_RUNTIME_ERROR;
+        if (!comm_hip(comm, ctx, hipStreamSynchronize(ctx->stream), "all_gather wait")) return RC_RUNTIME_ERROR;
+        return RC_OK;
+    }
+    Rccl *r = rccl();
+    if (!r->error.empty() || !r->AllGather || !comm->comm) { comm_fail(comm, ctx, r->error.empty() ? "communicator has no transport" : r->error); return RC_RUNTIME_ERROR; }
+    ncclResult_t e = r->AllGather(send, recv, bytes_per_rank, ncclUint8, comm->comm, ctx->stream);
+    if (e != ncclSuccess) { comm_fail(comm, ctx, r->GetErrorString ? r->GetErrorString(e) : "RCCL error"); return RC_RUNTIME_ERROR; }
+    return RC_OK;
+}
+
+// buf[i] = sum over the ranks of buf[i], in place, the same bits on every rank; elem_size 8: double, 4: float
+rc_status rc_comm_all_reduce_sum(rc_comm *comm, rc_context *ctx, void *buf, size_t count, int32_t elem_size) {
+    if (!comm || !ctx || (elem_size != 4 && elem_size != 8)) return RC_INVALID_ARGUMENT;
+    if (count == 0 || (comm->world == 1 && !comm->comm)) return RC_OK;
+    if (!buf) return RC_INVALID_ARGUMENT;
+    DeviceGuardB dg(comm->device);
+    const size_t bytes = count * (size_t)elem_size;
+    if (comm->host_reduce) {
+        comm->stage_in.resize(bytes);
+        if (!comm_hip(comm, ctx, hipMemcpyAsync(comm->stage_in.data(), buf, bytes, hipMemcpyDeviceToHost, ctx->stream), "all_reduce D2H")) return RC_RUNTIME_ERROR;
+        if (!comm_hip(comm, ctx, hipStreamSynchronize(ctx->stream), "all_reduce wait")) return RC_RUNTIME_ERROR;
+        if (comm->host_reduce(comm->user, comm->stage_in.data(), count, elem_size) != 0) {
+            comm_fail(comm, ctx, "the host's all_reduce callback reported an error");
+            return RC_RUNTIME_ERROR;
+        }
+        if (!comm_hip(comm, ctx, hipMemcpyAsync(buf, comm->stage_in.data(), bytes, hipMemcpyHostToDevice, ctx->stream), "all_reduce H2D")) return RC_RUNTIME_ERROR;
+        if (!comm_hip(comm, ctx, hipStreamSynchronize(ctx->stream), "all_reduce wait")) return RC_RUNTIME_ERROR;
+        return RC_OK;
+    }
+    Rccl *r = rccl();
+    if (!r->error.empty() || !r->AllReduce || !comm->comm) { comm_fail(comm, ctx, r->error.empty() ? "communicator has no transport" : r->error); return RC_RUNTIME_ERROR; }
+    ncclResult_t e = r->AllReduce(buf, buf, count, elem_size == 8 ? ncclDouble : ncclFloat, ncclSum, comm->comm, ctx->stream);
+    if (e != ncclSuccess) { comm_fail(comm, ctx, r->GetErrorString ? r->GetErrorString(e) : "RCCL error"); return RC_RUNTIME_ERROR; }
+    return RC_OK;
 }
 
 rc_status rc_comm_destroy(rc_comm *comm) {

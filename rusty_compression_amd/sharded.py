@@ -14,16 +14,23 @@ whose latency matters more than throughput.  Everything heavy stays local; what 
     SVD(B), pivoted QR(B), column ID coefficients                          redundantly on every rank (k x n: small)
     U_r = range_r U_b,  C_r = (range_r Q_b) R11                            local GEMMs: rows of U and of the ID's column matrix
 
-Outputs: row-sharded `range_q`, `u`, `qr_q`, `c`; replicated `s`, `vt`, `r`, `ind`, `z`.  The collectives are
-torch.distributed's (backend "nccl" = RCCL over xGMI on GPUs); under a gloo group (the tests: two ranks on one GPU) the two small
-buffers are staged through the host.  Compute goes through the C ABI like everything else: no CPU fallback."""
+Outputs: row-sharded `range_q`, `u`, `qr_q`, `c`; replicated `s`, `vt`, `r`, `ind`, `z`.
+
+The product path is ONE C-ABI call per rank, `rc_rsvd_id_row_sharded_*` (include/rusty_compression_amd.h), with an `rc_comm`
+built from the torch.distributed group: for an "nccl" group the library's own RCCL communicator (its unique id travels through
+the group once), for a gloo group (the tests: several ranks on one GPU) a host communicator whose two callbacks run the group's
+collectives on the staged host copies.  The step-by-step composition below (`ops=`) is the same algebra spelled with the
+one-matrix calls; tests/test_dist_cpu.py injects the CPU oracle there to check plumbing and TSQR algebra without a GPU, and the
+GPU test runs it beside the native call.  No CPU fallback in either."""
 from __future__ import annotations
 
 from dataclasses import dataclass
 from typing import Optional
 
-import torch
+import ctypes
+import traceback
 
+import torch
 
 
 class DeviceOps:
@@ -150,8 +157,114 @@ def sample_range_by_rank_sharded(a_local, k: int, p: int, seed: int, group=None,
     return ops.dot(q_r, block)                           # m_r x k
 
 
-def rsvd_id_row_sharded(a_local, k: int, p: int, seed: int, group=None, with_id: bool = True, ops=DeviceOps) -> ShardedRsvdId:
-    """Randomized SVD + pivoted QR + column ID of the row-sharded matrix (the cfg3 pipeline, one matrix over several GPUs)."""
+_GATHER_FN = ctypes.CFUNCTYPE(ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t)
+_REDUCE_FN = ctypes.CFUNCTYPE(ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int32)
+
+
+class Communicator:
+    """`rc_comm` of a torch.distributed group (see the module text): RCCL transport for "nccl" groups, host callbacks otherwise."""
+
+    def __init__(self, group=None, device=None):
+        from . import _lib
+
+        world, rank, dist = _world(group)
+        assert dist is not None and world > 1, "a communicator needs an initialised process group with more than one rank"
+        self.world, self.rank, self.group = world, rank, group
+        self.device = torch.cuda.current_device() if device is None else int(device)
+        self._h = ctypes.c_void_p()
+        lib = _lib.lib()
+        if dist.get_backend(group) == "nccl":
+            ident = torch.zeros(128, dtype=torch.uint8)
+            if rank == 0:
+                buf = (ctypes.c_char * 128)()
+                if lib.rc_comm_unique_id(buf) != _lib.RC_OK:
+                    raise _lib.HipRuntimeError("rc_comm_unique_id failed (librccl not available?)")
+                ident = torch.frombuffer(bytearray(buf.raw), dtype=torch.uint8).clone()
+            ident = ident.cuda(self.device)
+            dist.broadcast(ident, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+            raw = bytes(ident.cpu().numpy().tobytes())
+            st = lib.rc_comm_init(ctypes.byref(self._h), ctypes.c_int32(world), ctypes.c_int32(rank), raw, ctypes.c_int32(self.device))
+        else:
+            def gather(_user, send, recv, nbytes):
+                try:
+                    src = torch.frombuffer((ctypes.c_char * nbytes).from_address(send), dtype=torch.uint8)
+                    dst = torch.frombuffer((ctypes.c_char * (nbytes * world)).from_address(recv), dtype=torch.uint8)
+                    dist.all_gather_into_tensor(dst, src, group=group)
+                    return 0
+                except Exception:  # a callback must not unwind into C
+                    traceback.print_exc()
+                    return 1
+
+            def reduce(_user, buf, count, elem_size):
+                try:
+                    t = torch.frombuffer((ctypes.c_char * (count * elem_size)).from_address(buf), dtype=torch.float64 if elem_size == 8 else torch.float32)
+                    dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+                    return 0
+                except Exception:
+                    traceback.print_exc()
+                    return 1
+
+            self._cb = (_GATHER_FN(gather), _REDUCE_FN(reduce))  # kept alive as long as the communicator
+            lib.rc_comm_init_host.argtypes = [ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, _GATHER_FN, _REDUCE_FN, ctypes.c_void_p]
+            st = lib.rc_comm_init_host(ctypes.byref(self._h), world, rank, self.device, self._cb[0], self._cb[1], None)
+        if st != _lib.RC_OK:
+            raise _lib.HipRuntimeError(f"creating the communicator failed with status {st}")
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h.value:
+            from . import _lib
+
+            _lib.lib().rc_comm_destroy(self._h)
+            self._h = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+_comms = {}
+
+
+def communicator(group=None) -> Optional[Communicator]:
+    """The cached communicator of `group` (None for a single rank: the C call then takes a null communicator)."""
+    world, _, _ = _world(group)
+    if world == 1:
+        return None
+    key = (id(group), torch.cuda.current_device())
+    if key not in _comms:
+        _comms[key] = Communicator(group)
+    return _comms[key]
+
+
+def _rsvd_id_row_sharded_native(a_local, k: int, p: int, seed: int, group, with_id: bool) -> ShardedRsvdId:
+    from . import _lib
+    from .types import as_device
+
+    a = as_device(a_local)
+    m_r, n = a.shape
+    assert m_r >= k + p, f"every rank needs at least k + p = {k + p} rows, this one has {m_r}"
+    comm = communicator(group)
+    mk = lambda r, c: torch.empty((r, c), dtype=a.dtype, device=a.device)  # noqa: E731
+    rq, u, vt = mk(m_r, k), mk(m_r, k), mk(k, n)
+    s = torch.empty(k, dtype=_lib.real_dtype(a.dtype), device=a.device)
+    qq, r, ind = mk(m_r, k), mk(k, n), torch.empty(n, dtype=torch.int64, device=a.device)
+    c, z = (mk(m_r, k), mk(k, n)) if with_id else (None, None)
+    out = _lib.rc_rsvd_id_out(_lib.mat(rq), _lib.mat(u), ctypes.c_void_p(s.data_ptr()), _lib.mat(vt), _lib.mat(qq), _lib.mat(r),
+                              ctypes.c_void_p(ind.data_ptr()), _lib.mat(c), _lib.mat(z))
+    ctx = _lib.default_context()
+    fn = getattr(_lib.lib(), f"rc_rsvd_id_row_sharded_{_lib.suffix(a.dtype)}")
+    ctx.check(fn(comm._h if comm is not None else ctypes.c_void_p(None), ctx._h, _lib.mat(a), ctypes.c_int64(k), ctypes.c_int64(p),
+                 ctypes.c_uint64(seed), ctypes.byref(out)))
+    return ShardedRsvdId(rq, u, s, vt, qq, r, ind, c, z)
+
+
+def rsvd_id_row_sharded(a_local, k: int, p: int, seed: int, group=None, with_id: bool = True, ops=None) -> ShardedRsvdId:
+    """Randomized SVD + pivoted QR + column ID of the row-sharded matrix (the cfg3 pipeline, one matrix over several GPUs).
+    ops=None: the native call `rc_rsvd_id_row_sharded_*`; ops=DeviceOps (or an injected set of steps): the composition below."""
+    if ops is None:
+        return _rsvd_id_row_sharded_native(a_local, k, p, seed, group, with_id)
     a = ops.prepare(a_local)
     rq = sample_range_by_rank_sharded(a, k, p, seed, group, ops)
     kk = rq.shape[1]

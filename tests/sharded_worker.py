@@ -1,6 +1,7 @@
 """Worker of tests/test_gpu_sharded.py: one rank of the row-sharded rSVD + ID (rusty_compression_amd/sharded.py).
 Launched as `python tests/sharded_worker.py <out.npz>` with RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT set; every rank uses
-GPU 0 of the box (the test machine has one) and a gloo group, whose two small buffers the module stages through the host."""
+GPU 0 of the box (the test machine has one) and a gloo group: the native call gets a host communicator whose callbacks run the
+group's collectives on the library's staged host copies."""
 import os
 import sys
 
@@ -31,9 +32,14 @@ def main():
         a = test_matrix(m, n)
         rows = np.array_split(np.arange(m), world)[rank]
         a_loc = a[int(rows[0]):int(rows[-1]) + 1].contiguous()
-        res = sharded.rsvd_id_row_sharded(a_loc, k, p, seed)
+        dtype = getattr(torch, os.environ.get("SH_DTYPE", "float64"))
+        a_loc = a_loc.to(dtype)
+        res = sharded.rsvd_id_row_sharded(a_loc, k, p, seed)  # the native call rc_rsvd_id_row_sharded_* over a host communicator
         torch.cuda.synchronize()
-        np.savez(out, rows=rows, **{f: getattr(res, f).cpu().numpy() for f in ("range_q", "u", "s", "vt", "qr_q", "r", "ind", "c", "z")})
+        comp = sharded.rsvd_id_row_sharded(a_loc, k, p, seed, ops=sharded.DeviceOps)  # the same algebra from the one-matrix calls
+        torch.cuda.synchronize()
+        fields = ("range_q", "u", "s", "vt", "qr_q", "r", "ind", "c", "z")
+        np.savez(out, rows=rows, **{f: getattr(res, f).cpu().numpy() for f in fields}, **{"comp_" + f: getattr(comp, f).cpu().numpy() for f in fields})
     finally:
         dist.destroy_process_group()
 

@@ -72,6 +72,39 @@ def test_row_sharded_rsvd_id_matches_the_single_gpu_pipeline(world, tmp_path):
     assert rel(qq @ r, an[:, ind] - (an[:, ind] - rq @ (rq.T @ an[:, ind]))) <= 1e-10, "Q R = (range range^T A) P"
     assert rel(c, an[:, ind[:k]] - (an[:, ind[:k]] - rq @ (rq.T @ an[:, ind[:k]]))) <= 1e-9, "C = the selected columns of the projected matrix"
     assert abs(rel(c @ z, an) - rel(cid1.c.cpu().numpy() @ cid1.z.cpu().numpy(), an)) <= 1e-8
+    # the native call against the composition of one-matrix calls (same algebra, same kernels): same pivots, same factors
+    for q in parts:
+        assert np.array_equal(q["ind"][:k], q["comp_ind"][:k])
+        assert rel(q["s"], q["comp_s"]) <= 1e-12 and rel(q["r"], q["comp_r"]) <= 1e-10 and rel(q["z"], q["comp_z"]) <= 1e-8
+        assert rel(q["range_q"], q["comp_range_q"]) <= 1e-10 and rel(q["c"], q["comp_c"]) <= 1e-10
+
+
+def test_row_sharded_native_call_f32_two_ranks(tmp_path):
+    """f32 instantiation of rc_rsvd_id_row_sharded over two ranks: orthonormal global range, replicated outputs identical,
+    approximation error at the level of the single-GPU f32 pipeline."""
+    import torch
+
+    import rusty_compression_amd as rc
+    from tests.sharded_worker import test_matrix
+
+    m, n, k, p, seed = 1536, 896, 48, 8, 4
+    parts = _run_ranks(2, tmp_path, dict(SH_M=str(m), SH_N=str(n), SH_K=str(k), SH_P=str(p), SH_SEED=str(seed), SH_DTYPE="float32"))
+    for f in ("s", "vt", "r", "ind", "z"):
+        assert np.array_equal(parts[0][f], parts[1][f]), f
+    rq, u, c = (np.concatenate([q[f] for q in parts]).astype(np.float64) for f in ("range_q", "u", "c"))
+    s, vt, z, ind = (parts[0][f] for f in ("s", "vt", "z", "ind"))
+    assert rq.dtype == np.float64 and parts[0]["range_q"].dtype == np.float32
+    a = test_matrix(m, n).to(torch.float32)
+    an = a.cpu().numpy().astype(np.float64)
+    assert np.abs(rq.T @ rq - np.eye(k)).max() <= 5e-5 and np.abs(u.T @ u - np.eye(k)).max() <= 5e-5
+    q1 = rc.sample_range_by_rank(a, k, p, rc.Rng(seed))
+    svd1 = rc.SVD.compute_from_range_estimate(q1, a)
+    assert rel(s, svd1.s.cpu().numpy()) <= 1e-4
+    e_sh = rel((u * s.astype(np.float64)) @ vt.astype(np.float64), an)
+    e_1 = rel((svd1.u.cpu().numpy().astype(np.float64) * svd1.s.cpu().numpy().astype(np.float64)) @ svd1.vt.cpu().numpy().astype(np.float64), an)
+    assert abs(e_sh - e_1) <= 1e-4 and e_sh < 5e-3
+    assert sorted(ind.tolist()) == list(range(n))
+    assert rel(c @ z.astype(np.float64), an) < 1e-2
 
 
 def test_row_sharded_world_one_is_the_plain_pipeline():
@@ -92,3 +125,46 @@ def test_row_sharded_world_one_is_the_plain_pipeline():
     cid1 = qr1.column_id()
     e_sh, e_1 = rel(res.c.cpu().numpy() @ res.z.cpu().numpy(), an), rel(cid1.c.cpu().numpy() @ cid1.z.cpu().numpy(), an)
     assert abs(e_sh - e_1) <= 1e-8 and e_sh < 1e-2
+
+
+def test_rccl_collectives_and_the_sharded_call_on_a_one_rank_communicator():
+    """The RCCL transport of rc_comm_all_gather / rc_comm_all_reduce_sum (ncclAllGather, ncclAllReduce: a communicator of one
+    rank still goes through the library) and rc_rsvd_id_row_sharded_f64 with that communicator: same bits as comm == NULL."""
+    import ctypes
+
+    import torch
+
+    from rusty_compression_amd import _lib, batch, sharded
+    from tests.sharded_worker import test_matrix
+
+    comm = batch.Comm(1, 0, batch.Comm.unique_id())
+    try:
+        ctx, lib = _lib.default_context(), _lib.lib()
+        x = torch.arange(4096, dtype=torch.float64, device="cuda") * 0.5
+        y = torch.zeros_like(x)
+        ctx.check(lib.rc_comm_all_gather(comm._h, ctx._h, ctypes.c_void_p(x.data_ptr()), ctypes.c_void_p(y.data_ptr()), ctypes.c_size_t(x.numel() * 8)))
+        z = x.clone()
+        ctx.check(lib.rc_comm_all_reduce_sum(comm._h, ctx._h, ctypes.c_void_p(z.data_ptr()), ctypes.c_size_t(z.numel()), ctypes.c_int32(8)))
+        zf = x.to(torch.float32)
+        ctx.check(lib.rc_comm_all_reduce_sum(comm._h, ctx._h, ctypes.c_void_p(zf.data_ptr()), ctypes.c_size_t(zf.numel()), ctypes.c_int32(4)))
+        ctx.synchronize()
+        assert torch.equal(y, x) and torch.equal(z, x) and torch.equal(zf, x.to(torch.float32))
+        w, r = ctypes.c_int32(-1), ctypes.c_int32(-1)
+        assert lib.rc_comm_world(comm._h, ctypes.byref(w), ctypes.byref(r)) == 0 and (w.value, r.value) == (1, 0)
+
+        a = test_matrix(1024, 768)
+        k, p, seed = 64, 5, 3
+        plain = sharded.rsvd_id_row_sharded(a, k, p, seed)  # comm == NULL
+        mk = lambda rr, cc: torch.empty((rr, cc), dtype=a.dtype, device=a.device)  # noqa: E731
+        rq, u, vt, s = mk(1024, k), mk(1024, k), mk(k, 768), torch.empty(k, dtype=a.dtype, device=a.device)
+        none = _lib.mat(None)
+        out = _lib.rc_rsvd_id_out(_lib.mat(rq), _lib.mat(u), ctypes.c_void_p(s.data_ptr()), _lib.mat(vt), none, none, ctypes.c_void_p(None), none, none)
+        ctx.check(lib.rc_rsvd_id_row_sharded_f64(comm._h, ctx._h, _lib.mat(a), ctypes.c_int64(k), ctypes.c_int64(p), ctypes.c_uint64(seed), ctypes.byref(out)))
+        ctx.synchronize()
+        assert torch.equal(s, plain.s) and torch.equal(rq, plain.range_q) and torch.equal(u, plain.u) and torch.equal(vt, plain.vt)
+        # too few rows for k + p on this rank: the reference's assert!-style argument error, not a crash
+        import pytest as _pt
+        with _pt.raises(AssertionError):
+            ctx.check(lib.rc_rsvd_id_row_sharded_f64(comm._h, ctx._h, _lib.mat(a[:60].contiguous()), ctypes.c_int64(k), ctypes.c_int64(p), ctypes.c_uint64(seed), ctypes.byref(out)))
+    finally:
+        comm.close()
