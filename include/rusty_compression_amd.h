@@ -352,7 +352,7 @@ size_t rc_batch_packed_bytes(int64_t m, int64_t n, int64_t k, int32_t elem_size)
 rc_status rc_batch_shard_range(int64_t n_items, int32_t world, int32_t rank, int64_t *start, int64_t *count);
 /* Rank-k column ID of `count` same-shaped device matrices into the packed device buffer `packed`
  * (count * rc_batch_packed_bytes).  The matrices are spread over the nctx contexts (one HIP stream each, same device) and
- * advanced in lock step, one host wait per pivoting panel for ALL of them; results are identical to count calls of
+ * pipelined (each lane is waited for on its own event, first in, first out; idle lanes take the next matrix); results are identical to count calls of
  * rc_column_id_rank_*.  Blocking: returns when every factor is in `packed`.  Errors are reported on ctxs[0]. */
 rc_status rc_batch_column_id_f64(rc_context *const *ctxs, int32_t nctx, const rc_matrix *mats, int32_t count, int64_t k, void *packed);
 rc_status rc_batch_column_id_f32(rc_context *const *ctxs, int32_t nctx, const rc_matrix *mats, int32_t count, int64_t k, void *packed);

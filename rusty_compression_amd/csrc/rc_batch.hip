@@ -6,10 +6,12 @@
 // (src/qr.rs:354-362 via pivoted_qr, :169-184, :270-309).  The reference has no batch or communication layer: it is
 // single-process host code; SURVEY.md section 8(b) / 8(e) define these entry points.
 //
-// rc_batch_column_id_*: the matrices of one GPU are spread over the caller's contexts (one stream each) and advanced in
-// lock step: every lane issues one ?laqps panel, the host waits ONCE for all lanes (the panel length is data dependent),
-// every lane issues its panel-end kernels -- so the per-panel waits and the latency-bound pivot steps of different
-// matrices overlap.  Results land in one packed device buffer, which is exactly what rc_comm_gather moves.
+// rc_batch_column_id_*: the matrices of one GPU are spread over the caller's contexts (one stream each) and pipelined: every
+// lane carries an event behind its ?laqps panel (the panel length is data dependent, so the host has to look at its state),
+// the host serves the lanes first in, first out -- wait for that lane only, issue its panel-end kernels and its next panel,
+// or its C, Z, ind and the set-up of the lane's next matrix -- so the latency-bound pivot steps of some matrices overlap the
+// streaming kernels and the host-side launches of the others.  Results land in one packed device buffer, which is exactly
+// what rc_comm_gather moves.
 //
 // RCCL is opened at run time (dlopen) so that the library has no link-time dependency on it: hosts that never gather,
 // and the CPU-side symbol tests, do not need it.  Inside a PyTorch process the soname resolves to the copy torch loaded.
@@ -19,6 +21,8 @@
 #include <rccl/rccl.h>
 
 #include <algorithm>
+#include <atomic>
+#include <deque>
 #include <mutex>
 #include <thread>
 #include <vector>
@@ -97,9 +101,9 @@ void batch_column_id(rc_context *const *ctxs, int nctx, const rc_matrix *mats, i
         ~Cleanup() { for (auto &x : l) if (x.job) { qrb_end(x.job); x.job = nullptr; } }
     } cleanup{lanes};
     auto slot = [&](int idx) { return static_cast<char *>(packed) + (size_t)idx * per; };
-    // RC_BATCH_THREADS=1: one host thread per lane for the issue phases (measured slower than inline issue once the panels
+    // RC_BATCH_LOCKSTEP_THREADS=1 (lock-step schedule only): one host thread per lane for the issue phases (measured slower than inline issue once the panels
     // replay from hipGraphs: thread start-up + runtime locks cost more than the launches they overlap)
-    static const bool threaded = [] { const char *e = getenv("RC_BATCH_THREADS"); return e && atoi(e) != 0; }();
+    static const bool threaded = [] { const char *e = getenv("RC_BATCH_LOCKSTEP_THREADS"); return e && atoi(e) != 0; }();
     auto for_lanes = [&](auto &&pred, auto &&body) {
         std::vector<std::thread> th;
         std::vector<Error> errs((size_t)nctx, Error{RC_OK, ""});
@@ -126,48 +130,124 @@ void batch_column_id(rc_context *const *ctxs, int nctx, const rc_matrix *mats, i
         finish_column_id<T>(ln.c, ln.w, k, ln.tau, ln.ind, cm, z, ln.job);
         RC_HIP(hipMemcpyAsync(base + align8(((size_t)m * k + (size_t)k * n) * sizeof(T)), ln.ind, (size_t)n * sizeof(int64_t), hipMemcpyDeviceToDevice, ln.c->stream));
     };
-    for (int base = 0; base < count; base += nctx) {
-        int nact = 0;
-        for (int l = 0; l < nctx && base + l < count; ++l) {
-            Lane &ln = lanes[(size_t)l];
-            ln.c = ctxs[l];
-            ln.idx = base + l;
-            DeviceGuardB dg(ln.c->device);
-            ln.c->reset_arena();
-            ln.w = tmp_cm<T>(ln.c, m, n);
-            ln.tau = ln.c->template alloc<T>((size_t)k);
-            // (the permutation is built in a lane-owned buffer whose address repeats from matrix to matrix, so that the
-            // cached panel graphs of the blocked QRCP replay; it is copied into the packed slot at the end)
-            ln.ind = ln.c->template alloc<int64_t>((size_t)n);
-            copy_mat(ln.c, from_c<T>(mats[ln.idx]), ln.w);  // the reference's F-order working copy (pivoted_qr.rs:28-29)
-            if (ln.c->opt_blocked && geqp3_blocked_supported<T>(m, n, k)) {
-                ln.job = qrb_begin<T>(ln.c, ln.w, k, ln.ind, ln.tau);
-                ln.active = true;
-                ++nact;
-            } else {  // small shapes: the per-step chain, nothing to interleave
-                T *vn = ln.c->template alloc<T>((size_t)(2 * n));
-                geqp3_inplace(ln.c, ln.w, k, true, ln.ind, ln.tau, vn);
-                post(ln);
-                ln.active = false;
+    // set-up of the next matrix on a lane: working copy, then either the first panel of the blocked factorization (true: the
+    // lane has a panel in flight) or, for small shapes, the whole per-step chain (false: nothing to wait for)
+    auto start = [&](Lane &ln, int idx) -> bool {
+        ln.idx = idx;
+        DeviceGuardB dg(ln.c->device);
+        ln.c->reset_arena();
+        ln.w = tmp_cm<T>(ln.c, m, n);
+        ln.tau = ln.c->template alloc<T>((size_t)k);
+        // (the permutation is built in a lane-owned buffer whose address repeats from matrix to matrix, so that the
+        // cached panel graphs of the blocked QRCP replay; it is copied into the packed slot at the end)
+        ln.ind = ln.c->template alloc<int64_t>((size_t)n);
+        copy_mat(ln.c, from_c<T>(mats[ln.idx]), ln.w);  // the reference's F-order working copy (pivoted_qr.rs:28-29)
+        if (ln.c->opt_blocked && geqp3_blocked_supported<T>(m, n, k)) {
+            ln.job = qrb_begin<T>(ln.c, ln.w, k, ln.ind, ln.tau);
+            ln.active = true;
+            return true;
+        }
+        T *vn = ln.c->template alloc<T>((size_t)(2 * n));
+        geqp3_inplace(ln.c, ln.w, k, true, ln.ind, ln.tau, vn);
+        post(ln);
+        ln.active = false;
+        return false;
+    };
+    for (int l = 0; l < nctx; ++l) lanes[(size_t)l].c = ctxs[l];
+    // RC_BATCH_LOCKSTEP=1: the round-1 schedule (all lanes issue, ONE wait for all, all lanes finish), kept for comparison.
+    static const bool lockstep = [] { const char *e = getenv("RC_BATCH_LOCKSTEP"); return e && atoi(e) != 0; }();
+    if (lockstep) {
+        for (int base = 0; base < count; base += nctx) {
+            int nact = 0;
+            for (int l = 0; l < nctx && base + l < count; ++l) nact += start(lanes[(size_t)l], base + l) ? 1 : 0;
+            while (nact > 0) {
+                for_lanes([](Lane &ln) { return ln.active; }, [](Lane &ln) { qrb_issue(ln.job); });
+                // one wait for all lanes: an event on every stream first (see rc_synchronize_all)
+                std::vector<rc_context *> act;
+                for (auto &ln : lanes)
+                    if (ln.active) act.push_back(ln.c);
+                RC_REQUIRE(rc_synchronize_all(act.data(), (int32_t)act.size()) == RC_OK, RC_RUNTIME_ERROR, "batch_column_id: wait failed");
+                for_lanes([](Lane &ln) { return ln.active; }, [&](Lane &ln) {
+                    if (qrb_finish(ln.job)) {
+                        ln.active = false;
+                        post(ln);
+                        qrb_end(ln.job);
+                        ln.job = nullptr;
+                    }
+                });
+                nact = 0;
+                for (auto &ln : lanes) nact += ln.active ? 1 : 0;
             }
         }
-        while (nact > 0) {
-            for_lanes([](Lane &ln) { return ln.active; }, [](Lane &ln) { qrb_issue(ln.job); });
-            // one wait for all lanes: an event on every stream first (see rc_synchronize_all)
-            std::vector<rc_context *> act;
-            for (auto &ln : lanes)
-                if (ln.active) act.push_back(ln.c);
-            RC_REQUIRE(rc_synchronize_all(act.data(), (int32_t)act.size()) == RC_OK, RC_RUNTIME_ERROR, "batch_column_id: wait failed");
-            for_lanes([](Lane &ln) { return ln.active; }, [&](Lane &ln) {
+    } else {
+        // Pipeline: every lane carries an event behind its panel; the host serves the lanes in the order their panels were
+        // issued (first in, first out): wait for that lane only, enqueue its panel-end kernels and its next panel (or its C, Z,
+        // ind and the set-up of the lane's next matrix), go on to the next lane.  The lanes drift apart by the host time of one
+        // lane's launches, so the host-bound phases of some matrices (dozens of small launches) run while the latency-bound
+        // cooperative panels of the others occupy the GPU, instead of everything waiting for the slowest panel of a round.
+        auto mark = [&](Lane &ln) {
+            rc_context *c = ln.c;
+            if (!c->sync_ev) RC_HIP(hipEventCreateWithFlags(&c->sync_ev, hipEventDisableTiming));
+            RC_HIP(hipEventRecord(c->sync_ev, c->stream));
+        };
+        // RC_BATCH_THREADS issuing threads own disjoint sets of lanes and draw matrices from one counter.  Default 1: the batch
+        // is bound by the host's launch rate (~46 kernels + copies per matrix), but the runtime serialises launches of different
+        // threads -- 2 / 4 / 8 threads measured 2091 / 2056 / 2075 matrices/s against 2173 with one (8 x 4096 x 4096 f32, k = 64).
+        static const int want_threads = [] { const char *e = getenv("RC_BATCH_THREADS"); return e ? std::max(1, atoi(e)) : 1; }();
+        const int nthr = std::max(1, std::min({want_threads, nctx, count}));
+        std::atomic<int> next{0};
+        auto worker = [&](int l0, int l1) {
+            std::deque<int> fifo;
+            for (;;) {
+                for (int l = l0; l < l1; ++l) {  // idle lanes take the next matrices
+                    Lane &ln = lanes[(size_t)l];
+                    if (ln.active) continue;
+                    const int idx = next.fetch_add(1);
+                    if (idx >= count) break;
+                    if (start(ln, idx)) {
+                        DeviceGuardB dg(ln.c->device);
+                        qrb_issue(ln.job);
+                        mark(ln);
+                        fifo.push_back(l);
+                    }
+                }
+                if (fifo.empty()) {
+                    if (next.load() >= count) break;
+                    continue;
+                }
+                const int l = fifo.front();
+                Lane &ln = lanes[(size_t)l];
+                fifo.pop_front();
+                DeviceGuardB dg(ln.c->device);
+                RC_HIP(hipEventSynchronize(ln.c->sync_ev));
                 if (qrb_finish(ln.job)) {
-                    ln.active = false;
+                    ln.active = false;  // (the lane is handed its next matrix at the top of the loop)
                     post(ln);
                     qrb_end(ln.job);
                     ln.job = nullptr;
+                } else {
+                    qrb_issue(ln.job);
+                    mark(ln);
+                    fifo.push_back(l);
                 }
-            });
-            nact = 0;
-            for (auto &ln : lanes) nact += ln.active ? 1 : 0;
+            }
+        };
+        if (nthr == 1) {
+            worker(0, nctx);
+        } else {
+            std::vector<std::thread> th;
+            std::vector<Error> errs((size_t)nthr, Error{RC_OK, ""});
+            for (int t = 0; t < nthr; ++t) {
+                const int l0 = (int)((int64_t)nctx * t / nthr), l1 = (int)((int64_t)nctx * (t + 1) / nthr);
+                th.emplace_back([&, t, l0, l1] {
+                    try { worker(l0, l1); }
+                    catch (const Error &e) { errs[(size_t)t] = e; next.store(count); }
+                    catch (const std::exception &e) { errs[(size_t)t] = Error{RC_RUNTIME_ERROR, e.what()}; next.store(count); }
+                });
+            }
+            for (auto &t : th) t.join();
+            for (auto &e : errs)
+                if (e.code != RC_OK) throw e;
         }
     }
     std::vector<rc_context *> all(ctxs, ctxs + std::min(nctx, count));
