@@ -519,4 +519,56 @@ AdaptiveResult<T> sample_range_adaptive(const DeviceMatrix<T> &op, double rel_to
     return out;
 }
 
+// ---- one matrix sharded by rows over several ranks (rc_rsvd_id_row_sharded_*; the reference is single-process) ----------
+// A communicator over RCCL (one process per GPU) or over the host's own communication layer (callbacks on host pointers).
+class Comm {
+  public:
+    static Comm rccl(int32_t world, int32_t rank, const void *id128, int32_t device) {
+        Comm c;
+        if (rc_comm_init(&c.raw_, world, rank, id128, device) != RC_OK) throw HipRuntimeError(rc_comm_last_error_message(nullptr));
+        return c;
+    }
+    static Comm host(int32_t world, int32_t rank, int32_t device, rc_host_all_gather_fn all_gather, rc_host_all_reduce_sum_fn all_reduce_sum, void *user) {
+        Comm c;
+        if (rc_comm_init_host(&c.raw_, world, rank, device, all_gather, all_reduce_sum, user) != RC_OK) throw AssertionFailed("rc_comm_init_host: bad arguments");
+        return c;
+    }
+    Comm(Comm &&o) noexcept : raw_(o.raw_) { o.raw_ = nullptr; }
+    Comm &operator=(Comm &&o) noexcept { if (this != &o) { rc_comm_destroy(raw_); raw_ = o.raw_; o.raw_ = nullptr; } return *this; }
+    Comm(const Comm &) = delete;
+    Comm &operator=(const Comm &) = delete;
+    ~Comm() { rc_comm_destroy(raw_); }
+    rc_comm *raw() const { return raw_; }
+
+  private:
+    Comm() = default;
+    rc_comm *raw_ = nullptr;
+};
+// this rank's rows of the global factors (range_q, u, qr_q, c) and the replicated ones (s, vt, r, ind, z)
+template <typename T>
+struct ShardedRsvdId {
+    DeviceMatrix<T> range_q, u;
+    DeviceBuffer<T> s;
+    DeviceMatrix<T> vt, qr_q, r;
+    DeviceIndex ind;
+    DeviceMatrix<T> c, z;
+};
+inline rc_status rsvd_id_row_sharded_raw(rc_comm *cm, rc_context *cx, rc_matrix a, int64_t k, int64_t p, uint64_t seed, const rc_rsvd_id_out *o, double) {
+    return rc_rsvd_id_row_sharded_f64(cm, cx, a, k, p, seed, o);
+}
+inline rc_status rsvd_id_row_sharded_raw(rc_comm *cm, rc_context *cx, rc_matrix a, int64_t k, int64_t p, uint64_t seed, const rc_rsvd_id_out *o, float) {
+    return rc_rsvd_id_row_sharded_f32(cm, cx, a, k, p, seed, o);
+}
+// a_local: the m_r x n row block of this rank (m_r >= k + p); comm == nullptr: one rank.  Real scalar types.
+template <typename T>
+ShardedRsvdId<T> rsvd_id_row_sharded(const Comm *comm, const DeviceMatrix<T> &a_local, int64_t k, int64_t p, uint64_t seed) {
+    const Context &cx = a_local.ctx();
+    const int64_t mr = a_local.nrows(), n = a_local.ncols();
+    ShardedRsvdId<T> out{DeviceMatrix<T>(cx, mr, k), DeviceMatrix<T>(cx, mr, k), DeviceBuffer<T>(cx, (std::size_t)k), DeviceMatrix<T>(cx, k, n), DeviceMatrix<T>(cx, mr, k),
+                         DeviceMatrix<T>(cx, k, n), DeviceIndex(cx, (std::size_t)n), DeviceMatrix<T>(cx, mr, k), DeviceMatrix<T>(cx, k, n)};
+    rc_rsvd_id_out o{out.range_q.view(), out.u.view(), out.s.data(), out.vt.view(), out.qr_q.view(), out.r.view(), out.ind.data(), out.c.view(), out.z.view()};
+    cx.check(rsvd_id_row_sharded_raw(comm ? comm->raw() : nullptr, cx.raw(), a_local.view(), k, p, seed, &o, T()));
+    return out;
+}
+
 }  // namespace rusty_compression

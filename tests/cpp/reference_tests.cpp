@@ -2,13 +2,17 @@
 //   src/pivoted_qr.rs:193-317, src/qr.rs:418-616, src/svd.rs:193-321, src/col_interp_decomp.rs:163-242,
 //   src/row_interp_decomp.rs:163-236, src/permutation.rs:187-240.
 // Same test names, same matrices (the reference's generator recipe, seeded), same assertions and tolerances, for all four
-// scalar types of the reference (f32, f64, c32, c64): 11 tests x 4 types x 2 shapes + the 2 permutation tests = 90.  This is the COMPILED twin of bindings/rust/tests/reference_tests.rs (the
+// scalar types of the reference (f32, f64, c32, c64): 11 tests x 4 types x 2 shapes + the 2 permutation tests = 90, plus one test of the row-sharded call (two ranks = two threads, host communicator).  This is the COMPILED twin of bindings/rust/tests/reference_tests.rs (the
 // Rust crate cannot be built in this repository's container): tests/test_gpu_parity.py builds it and runs it on the GPU box,
 // the CPU suite compiles and links it.  Prints one line per test and exits non-zero if any assertion failed.
 #include <cmath>
+#include <condition_variable>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
+#include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "rusty_compression.hpp"
@@ -238,6 +242,83 @@ static void permutation_tests(const Context &ctx) {
     });
 }
 
+// ---- not a reference test: the row-sharded call driven from C++ by two ranks = two threads of this process, each with its own
+// context on GPU 0 and a HOST communicator whose callbacks exchange through shared memory (what an MPI host would plug in)
+struct TwoRankBus {
+    std::mutex mu;
+    std::condition_variable cv;
+    int arrived = 0, generation = 0;
+    std::vector<char> gather;
+    std::vector<double> sum;
+    void barrier(std::unique_lock<std::mutex> &lk) {
+        const int gen = generation;
+        if (++arrived == 2) { arrived = 0; ++generation; cv.notify_all(); }
+        else cv.wait(lk, [&] { return generation != gen; });
+    }
+};
+struct RankView { TwoRankBus *bus; int rank; };
+static int32_t bus_all_gather(void *user, const void *send, void *recv, size_t bytes) {
+    auto *rv = static_cast<RankView *>(user);
+    std::unique_lock<std::mutex> lk(rv->bus->mu);
+    if (rv->bus->gather.size() != 2 * bytes) rv->bus->gather.assign(2 * bytes, 0);
+    std::memcpy(rv->bus->gather.data() + (size_t)rv->rank * bytes, send, bytes);
+    rv->bus->barrier(lk);
+    std::memcpy(recv, rv->bus->gather.data(), 2 * bytes);
+    rv->bus->barrier(lk);  // nobody overwrites the buffer before both have read it
+    return 0;
+}
+static int32_t bus_all_reduce(void *user, void *buf, size_t count, int32_t elem_size) {
+    auto *rv = static_cast<RankView *>(user);
+    if (elem_size != 8) return 1;
+    double *x = static_cast<double *>(buf);
+    std::unique_lock<std::mutex> lk(rv->bus->mu);
+    if (rv->rank == 0) rv->bus->sum.assign(x, x + count);
+    rv->bus->barrier(lk);
+    if (rv->rank == 1) for (size_t i = 0; i < count; ++i) rv->bus->sum[i] += x[i];  // one fixed order: the same bits on both ranks
+    rv->bus->barrier(lk);
+    std::memcpy(x, rv->bus->sum.data(), count * sizeof(double));
+    rv->bus->barrier(lk);
+    return 0;
+}
+static void sharded_test(const Context &ctx) {
+    run_test("row_sharded_rsvd_id_two_ranks_over_a_host_communicator", [&] {
+        const int64_t m = 640, n = 300, k = 24, p = 6;
+        const uint64_t seed = 11;
+        auto a = random_approximate_low_rank_matrix<double>(ctx, m, n, 1.0, 1e-9, seed_of("sharded"));
+        auto ah = a.to_host();
+        auto range1 = sample_range_by_rank(a, k, p, seed);
+        auto svd1 = SVD<double>::compute_from_range_estimate(range1, a);
+        auto s1 = svd1.s.to_host();
+        TwoRankBus bus;
+        std::vector<double> s[2], z[2];
+        std::vector<int64_t> ind[2];
+        std::string err[2];
+        auto rank_body = [&](int rank) {
+            try {
+                Context cx(0);
+                RankView rv{&bus, rank};
+                Comm comm = Comm::host(2, rank, 0, bus_all_gather, bus_all_reduce, &rv);
+                const int64_t r0 = rank * (m / 2), rows = m / 2;
+                auto al = DeviceMatrix<double>::from_host(cx, ah.data() + (size_t)r0 * n, rows, n);
+                auto res = rsvd_id_row_sharded(&comm, al, k, p, seed);
+                cx.synchronize();
+                s[rank] = res.s.to_host();
+                z[rank] = res.z.to_host();
+                ind[rank] = res.ind.to_host();
+            } catch (const std::exception &e) { err[rank] = e.what(); }
+        };
+        std::thread t1(rank_body, 1);
+        rank_body(0);
+        t1.join();
+        CHECK(err[0].empty() && err[1].empty());
+        if (!err[0].empty() || !err[1].empty()) { std::printf("    rank errors: '%s' '%s'\n", err[0].c_str(), err[1].c_str()); return; }
+        CHECK(s[0] == s[1] && z[0] == z[1] && ind[0] == ind[1]);  // replicated outputs: the same bits
+        double worst = 0;
+        for (int64_t i = 0; i < k; ++i) worst = std::fmax(worst, std::fabs(s[0][(size_t)i] - s1[(size_t)i]) / s1[0]);
+        CHECK(worst <= 1e-10);  // singular values of the single-context pipeline with the same Omega stream
+    });
+}
+
 int main() {
     Context ctx(0);
     group<double>(ctx, 100, 50, "thin");
@@ -249,6 +330,7 @@ int main() {
     group<c64>(ctx, 50, 100, "thick");
     group<c32>(ctx, 50, 100, "thick");
     permutation_tests(ctx);
+    sharded_test(ctx);
     std::printf("%d tests, %d failed\n", tests_run, failures);
     return failures ? 1 : 0;
 }

@@ -78,7 +78,7 @@ def build_cpp_mirror_examples(out_dir, source="mirror_examples.cpp"):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     exe = os.path.join(str(out_dir), os.path.splitext(source)[0])
     libdir = os.path.dirname(_lib.LIB_PATH)
-    cmd = ["g++", "-std=c++17", "-O1", "-Wall", "-Wextra", "-Werror", "-I" + os.path.join(root, "include"),
+    cmd = ["g++", "-std=c++17", "-pthread", "-O1", "-Wall", "-Wextra", "-Werror", "-I" + os.path.join(root, "include"),
            os.path.join(root, "tests", "cpp", source), "-o", exe, "-L" + libdir, "-lrusty_compression_amd",
            "-Wl,-rpath," + libdir, "-Wl,-rpath-link,/opt/rocm/lib"]
     res = subprocess.run(cmd, capture_output=True, text=True, timeout=300)
