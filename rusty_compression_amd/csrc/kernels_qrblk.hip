@@ -841,8 +841,15 @@ __global__ __launch_bounds__(512, WPE) void k_qrb_coop(QrbCoopArgs<T> a) {
                     }
                 }
             }
+            // The posting wave drains its write-through stores itself: on gfx950 a workgroup barrier waits for LDS traffic only
+            // (s_waitcnt lgkmcnt(0); s_barrier -- no vmcnt(0) outside threadgroup-split mode), and the header below is written by
+            // ANOTHER wave.  Without this wait the header could overtake the column under memory load: a reader then fetched a
+            // column with a few rows of the posting two steps earlier, formed a slightly different reflector than the other
+            // workgroups, and the v_t^T v_k it recorded made the panel's T factor wrong (seen once in ~1000 matrices, and only
+            // with streaming kernels of other matrices running beside the panel).
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
-        // the column's write-through stores have completed (the barrier waits for vmcnt(0)) before the header is written
+        // the column's write-through stores have completed (drained by their wave, above) before the header is written
         __syncthreads();
         RC_QTICK(1)
         if (wv == 0) {
@@ -1506,7 +1513,7 @@ bool qrb_finish(BlockedQrcpJob<T> *J) {
         J->panels.push_back({j0, kb, tsave});
     }
     static const int dbg = env_int_b("RC_QRCP_DEBUG", 0);
-    if (dbg) fprintf(stderr, "qrb panel j0=%lld kb=%d/%d ncand=%d noncand=%d lsticc=%d stop_tau=%d cwant=%lld coop=%d\n", (long long)j0, kb, J->nbp, h.ncand, h.have_noncand, h.lsticc, h.stop_tau, (long long)J->cwant, coop ? 1 : 0);
+    if (dbg) fprintf(stderr, "qrb panel w=%p j0=%lld kb=%d/%d ncand=%d noncand=%d lsticc=%d stop_tau=%d cwant=%lld coop=%d pad0=%d fallbacks=%d\n", (void *)J->w.p, (long long)j0, kb, J->nbp, h.ncand, h.have_noncand, h.lsticc, h.stop_tau, (long long)J->cwant, coop ? 1 : 0, h.pad0, J->coop_fallbacks);
     if (h.stop_tau && kb < J->nbp) J->cwant = std::min<int64_t>(n, kb < J->nbp / 2 ? J->cwant * 2 : J->cwant * 3 / 2);
     J->j0 += kb;
     return J->j0 >= J->kmax;

@@ -222,8 +222,11 @@ __global__ __launch_bounds__(512) void k_wq_coop(WqCoopArgs<T> a) {
                 }
             }
         }
-        // every store of the candidate column has completed (the barrier waits for vmcnt(0), and these are
-        // write-through stores at agent scope) before the header that announces it is written
+        // Every store of the candidate column has completed before the header that announces it is written: the storing waves
+        // drain their write-through stores themselves -- on gfx950 a workgroup barrier waits for LDS traffic only (s_waitcnt
+        // lgkmcnt(0); s_barrier, no vmcnt(0) outside threadgroup-split mode) and the header is written by another wave, so under
+        // memory load it could overtake the column (kernels_qrblk.hip, k_qrb_coop, has the failure this caused there).
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         RC_TICK(1)
         if (wv == 0) {
