@@ -225,6 +225,12 @@ void check_view(const rc_matrix &m, const char *name, bool allow_null = false) {
 __global__ void k_or_flag(int *dst, const int *src) {
     if (threadIdx.x == 0 && blockIdx.x == 0 && *src) atomicOr(dst, *src);
 }
+// (certificate and health words are set by a kernel of the library on the context's stream, not by hipMemset*: with 16 contexts
+// replaying graphs at once, words cleared through the runtime's memset path were read back as byte patterns -- 0x01010101,
+// 0x02020202, 0x9f9f9f9f, the same on every context of a round -- although every output was bit-identical to the eager run)
+__global__ void k_set_word(int *dst, int v) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) *dst = v;
+}
 
 // Runs `fast(flag)` (which ORs failure bits into the device int `flag`) and reports whether
 // its result may be kept.  Outside graph capture the flag is read back (one small sync) so
@@ -232,7 +238,7 @@ __global__ void k_or_flag(int *dst, const int *src) {
 template <typename F>
 bool run_certified(rc_context *c, F &&fast) {
     int *flag = c->alloc<int>(1);
-    RC_HIP(hipMemsetAsync(flag, 0, sizeof(int), c->stream));
+    hipLaunchKernelGGL(k_set_word, dim3(1), dim3(64), 0, c->stream, flag, 0);
     fast(flag);
     if (c->capturing) {
         hipLaunchKernelGGL(k_or_flag, dim3(1), dim3(64), 0, c->stream, c->health_word(), flag);
@@ -1006,11 +1012,13 @@ rc_status rc_get_health(rc_context *ctx, int32_t *word) {
     DeviceGuard dg(ctx->device);
     *word = 0;
     if (!ctx->health) return RC_OK;
-    hipError_t e = hipStreamSynchronize(ctx->stream);
+    // read and clear on the context's own stream (pinned read-back, then a one-thread kernel): no null-stream traffic
     int h = 0;
-    if (e == hipSuccess) e = hipMemcpy(&h, ctx->health, sizeof(int), hipMemcpyDeviceToHost);
-    if (e == hipSuccess) e = hipMemset(ctx->health, 0, sizeof(int));
-    if (e != hipSuccess) { ctx->last_error = hipGetErrorString(e); return RC_RUNTIME_ERROR; }
+    try {
+        read_back(ctx, ctx->health, &h, 1);
+        hipLaunchKernelGGL(k_set_word, dim3(1), dim3(64), 0, ctx->stream, ctx->health, 0);
+        RC_HIP(hipStreamSynchronize(ctx->stream));
+    } catch (const Error &e) { ctx->last_error = e.msg; return e.code; }
     *word = h;
     return RC_OK;
 }
