@@ -110,6 +110,10 @@ __device__ inline unsigned tagged_get(const unsigned *p, unsigned e) {  // 0 = n
     return (w >> 8) == (e & 0xffffffu) ? (w & 0xffu) : 0u;
 }
 
+__global__ void k_clear_words(unsigned *p, int n) {
+    for (int i = threadIdx.x; i < n; i += blockDim.x) p[i] = 0u;
+}
+
 // ---------------------------------------------------------------------------
 // LDS-resident one-sided Jacobi.  LPP lanes own one column pair and keep NE = ceil(n / LPP)
 // rows of both columns in registers; with LPP = 4 a 128 x 128 core needs only 4 waves
@@ -609,6 +613,12 @@ static void launch_lds_impl(rc_context *c, Mat<T> g, Mat<T> uc, T *s, Mat<T> vc,
     if (fused) {
         unsigned *vsync = c->alloc<unsigned>((size_t)n + 1);
         unsigned long long *chk = c->alloc<unsigned long long>((size_t)max_sweeps * (N - 1) * (N / 2));
+        // The tagged words are cleared before every launch: a word counts as "published" when its upper 24 bits equal the launch's
+        // epoch, and workspace memory that is new to the context (first call, arena growth) holds whatever its last owner left --
+        // on a context's first launch (epoch 0 until round 2) any small integer there passed for a sweep count or a sorted
+        // position, and the consumer wrote V's columns to the wrong places without noticing (seen as one wrong `vt` among 16
+        // contexts' first calls).  The epoch itself now starts at a per-context pseudo-random value (rc_context::epoch_word).
+        hipLaunchKernelGGL(k_clear_words, dim3(1), dim3(256), 0, c->stream, vsync, n + 1);
         hipLaunchKernelGGL(kern, dim3(2), dim3(threads), lds, c->stream, g, log, sweeps, uc, s, order, max_sweeps, 1, vsync, chk, c->epoch_word(), vc, c->health_word(), ld);
     } else {
         hipLaunchKernelGGL(kern, dim3(1), dim3(threads), lds, c->stream, g, log, sweeps, uc, s, order, max_sweeps, 0, (unsigned *)nullptr, (unsigned long long *)nullptr,

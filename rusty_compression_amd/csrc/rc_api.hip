@@ -5,6 +5,11 @@
 // loops and one batched triangular solve instead of per-column ?trtrs calls.
 #include "rc_common.hpp"
 
+#include <unistd.h>
+
+#include <atomic>
+#include <chrono>
+
 #include <algorithm>
 #include <cmath>
 
@@ -115,7 +120,15 @@ int *rc_context::health_word() {
 unsigned *rc_context::epoch_word() {
     if (!epoch) {
         RC_HIP(hipMalloc(reinterpret_cast<void **>(&epoch), sizeof(unsigned)));
-        RC_HIP(hipMemset(epoch, 0, sizeof(unsigned)));
+        // a different, non-zero starting epoch for every context of the process (and of other processes): the records and tagged
+        // words of the fused Jacobi are keyed by it, and workspace memory travels between contexts through the allocator
+        static std::atomic<unsigned> serial{0};
+        const unsigned long long mix = (unsigned long long)std::chrono::steady_clock::now().time_since_epoch().count() * 0x9e3779b97f4a7c15ull ^
+                                       (unsigned long long)(uintptr_t)this * 0xd1342543de82ef95ull ^ ((unsigned long long)(++serial) << 40) ^
+                                       (unsigned long long)getpid() * 0xff51afd7ed558ccdull;
+        unsigned e0 = (unsigned)(mix >> 29) & 0x7fffffu;  // 23 bits: far from the 24-bit wrap
+        if (e0 == 0) e0 = 1;
+        RC_HIP(hipMemcpy(epoch, &e0, sizeof(unsigned), hipMemcpyHostToDevice));
     }
     return epoch;
 }

@@ -1336,6 +1336,48 @@ def test_wide_coop_qrcp_many_streams_in_flight():
         ln["ctx"].close()
 
 
+def test_first_call_of_fresh_contexts_on_recycled_memory_matches_a_warm_context():
+    """The first call of a context runs on workspace memory the allocator hands out fresh -- here memory that was just released
+    full of small integers.  The fused Jacobi's tagged words (sweep count, sorted positions: "(epoch << 8) | payload") used to be
+    trusted uncleared, and a context's first epoch was 0: such integers passed for published values and V's columns went to the
+    wrong places (one wrong `vt` among 16 contexts' first calls at cfg3 size, nothing flagged).  Every fresh context must
+    reproduce the warm context's factors bit for bit."""
+    import ctypes
+
+    from rusty_compression_amd import _lib
+
+    m, n, k, p = 4096, 4096, 128, 5
+    a = rc.random_gaussian((m, n), rc.Rng(77), torch.float64)
+
+    def run(ctx):
+        mk = lambda r, c: torch.zeros((r, c), dtype=torch.float64, device="cuda")  # noqa: E731
+        b = dict(range_q=mk(m, k), u=mk(m, k), s=torch.zeros(k, dtype=torch.float64, device="cuda"), vt=mk(k, n), qr_q=mk(m, k), qr_r=mk(k, n),
+                 qr_ind=torch.zeros(n, dtype=torch.int64, device="cuda"), id_c=mk(m, k), id_z=mk(k, n))
+        out = _lib.rc_rsvd_id_out(_lib.mat(b["range_q"]), _lib.mat(b["u"]), ctypes.c_void_p(b["s"].data_ptr()), _lib.mat(b["vt"]), _lib.mat(b["qr_q"]),
+                                  _lib.mat(b["qr_r"]), ctypes.c_void_p(b["qr_ind"].data_ptr()), _lib.mat(b["id_c"]), _lib.mat(b["id_z"]))
+        ctx.call("rc_rsvd_id_f64", _lib.mat(a), ctypes.c_int64(k), ctypes.c_int64(p), _lib.mat(None), ctypes.c_uint64(7), ctypes.byref(out))
+        ctx.synchronize()
+        return b
+
+    warm = _lib.Context(torch.cuda.current_device(), torch.cuda.current_stream().cuda_stream)
+    run(warm)
+    want = run(warm)
+    an = npy(a)
+    assert rel((npy(want["u"]) * npy(want["s"])) @ npy(want["vt"]), npy(want["range_q"]) @ (npy(want["range_q"]).T @ an)) <= 1e-10
+    for i in range(10):
+        junk = [torch.full((64 << 20,), 1 + (i + j) % 200, dtype=torch.int32, device="cuda") for j in range(4)]  # 1 GiB of small integers
+        torch.cuda.synchronize()
+        del junk
+        torch.cuda.empty_cache()  # back to the driver: the library's next hipMalloc may get these pages
+        ctx = _lib.Context(torch.cuda.current_device(), torch.cuda.current_stream().cuda_stream)
+        got = run(ctx)
+        assert ctx.get_health() == 0
+        for f in want:
+            assert torch.equal(got[f], want[f]), f"fresh context {i}: {f} differs from the warm context's"
+        ctx.close()
+    warm.close()
+
+
 def test_cpp_mirror_runs_the_reference_examples(tmp_path):
     """include/rusty_compression.hpp (compiled host side over the C ABI) running the reference's two
     example programs (examples/interpolative_decomposition.rs, examples/adaptive_sampling.rs)."""
