@@ -8,7 +8,8 @@ import rusty_compression_amd as rc
 from rusty_compression_amd import batch
 
 ROUNDS = int(os.environ.get("ROUNDS", "100"))
-mats = [rc.random_gaussian((4096, 4096), rc.Rng(500 + i), torch.float32) for i in range(8)]
+NB = int(os.environ.get("NB", "8"))
+mats = [rc.random_gaussian((4096, 4096), rc.Rng(500 + i), torch.float32) for i in range(NB)]
 want = [batch.column_id_rank(a, 64) for a in mats]
 again = [batch.column_id_rank(a, 64) for a in mats]
 for i, (w, g) in enumerate(zip(want, again)):

@@ -9,6 +9,8 @@ import rusty_compression_amd as rc
 from rusty_compression_amd import _lib
 
 LANES, ROUNDS = int(os.environ.get("LANES", "16")), int(os.environ.get("ROUNDS", "40"))
+SEEDS = int(os.environ.get("SEEDS", "0"))  # 1: every lane its own Omega stream (lanes drift apart: GEMMs of one beside the cooperative QRCP of another)
+REPS = int(os.environ.get("REPS", "1"))    # graph launches per lane and round, in shuffled lane order, before the round is compared
 m = n = int(os.environ.get("N", "8192")); k, p = 128, 5
 dt = torch.float64
 a = rc.random_gaussian((m, n), rc.Rng(11), dt)
@@ -23,14 +25,17 @@ for s in range(LANES):
                  qr_ind=torch.zeros(n, dtype=torch.int64, device="cuda"), id_c=mk(m, k), id_z=mk(k, n))
         out = _lib.rc_rsvd_id_out(_lib.mat(b["range_q"]), _lib.mat(b["u"]), ctypes.c_void_p(b["s"].data_ptr()), _lib.mat(b["vt"]), _lib.mat(b["qr_q"]),
                                   _lib.mat(b["qr_r"]), ctypes.c_void_p(b["qr_ind"].data_ptr()), _lib.mat(b["id_c"]), _lib.mat(b["id_z"]))
-        call = lambda ctx=ctx, out=out: ctx.call("rc_rsvd_id_f64", _lib.mat(a), ctypes.c_int64(k), ctypes.c_int64(p), _lib.mat(None), ctypes.c_uint64(7), ctypes.byref(out))
+        call = lambda ctx=ctx, out=out, s=s: ctx.call("rc_rsvd_id_f64", _lib.mat(a), ctypes.c_int64(k), ctypes.c_int64(p), _lib.mat(None), ctypes.c_uint64(7 + (s if SEEDS else 0)), ctypes.byref(out))
         ctx.set_option(_lib.RC_OPT_CONCURRENCY_HINT, LANES)
         call(); ctx.synchronize()
         graph = ctypes.c_void_p(None)
         ctx.check(lib.rc_graph_begin_capture(ctx._h)); call(); ctx.check(lib.rc_graph_end_capture(ctx._h, ctypes.byref(graph)))
         lanes.append(dict(ctx=ctx, st=st, b=b, out=out, graph=graph))
-ref = {f: t.clone() for f, t in lanes[0]["b"].items()}
-for i, ln in enumerate(lanes[1:], 1):
+refs = [{f: t.clone() for f, t in ln["b"].items()} for ln in lanes]
+ref = refs[0]
+import random
+rng = random.Random(5)
+for i, ln in enumerate(lanes[1:] if not SEEDS else [], 1):
     for f, t in ln["b"].items():
         if not torch.equal(t, ref[f]):
             d = (t.double() - ref[f].double()).abs()
@@ -41,15 +46,19 @@ for r in range(ROUNDS):
     for ln in lanes:
         for t in ln["b"].values(): t.zero_()
     torch.cuda.synchronize()
-    for ln in lanes: ln["ctx"].check(lib.rc_graph_launch(ln["ctx"]._h, ln["graph"]))
+    for _ in range(REPS):
+        order = list(range(LANES))
+        if REPS > 1: rng.shuffle(order)
+        for i in order: lanes[i]["ctx"].check(lib.rc_graph_launch(lanes[i]["ctx"]._h, lanes[i]["graph"]))
     for ln in lanes: ln["ctx"].synchronize()
     for i, ln in enumerate(lanes):
         h = ln["ctx"].get_health()
         if h: print(f"round {r} lane {i}: health {h:#x}")
         for f, t in ln["b"].items():
-            if not torch.equal(t, ref[f]):
+            want = refs[i][f] if SEEDS else ref[f]
+            if not torch.equal(t, want):
                 bad += 1
-                d = (t.double() - ref[f].double()).abs()
+                d = (t.double() - want.double()).abs()
                 print(f"round {r} lane {i} {f}: {int((d != 0).sum())} entries differ, max |diff| {d.max().item():.3e}", flush=True)
     if bad > 12: break
 print("lanes", LANES, "rounds", r + 1, "mismatching outputs", bad)
