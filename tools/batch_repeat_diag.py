@@ -9,15 +9,17 @@ from rusty_compression_amd import batch
 
 ROUNDS = int(os.environ.get("ROUNDS", "100"))
 NB = int(os.environ.get("NB", "8"))
-mats = [rc.random_gaussian((4096, 4096), rc.Rng(500 + i), torch.float32) for i in range(NB)]
-want = [batch.column_id_rank(a, 64) for a in mats]
-again = [batch.column_id_rank(a, 64) for a in mats]
+M, N, K = (int(os.environ.get(k, d)) for k, d in (("M", 4096), ("N", 4096), ("K", 64)))
+DT = getattr(torch, os.environ.get("DTYPE", "float32"))
+mats = [rc.random_gaussian((M, N), rc.Rng(500 + i), DT) for i in range(NB)]
+want = [batch.column_id_rank(a, K) for a in mats]
+again = [batch.column_id_rank(a, K) for a in mats]
 for i, (w, g) in enumerate(zip(want, again)):
     print("one-matrix call repeats:", i, all(torch.equal(x, y) for x, y in zip(w, g)))
 bad = 0
 for r in range(ROUNDS):
     print(f'== round {r}', file=sys.stderr, flush=True)
-    out = batch.batch_column_id(mats, 64)
+    out = batch.batch_column_id(mats, K)
     for i, ((c, z, ind), (c1, z1, i1)) in enumerate(zip(out, want)):
         for name, x, y in (("ind", ind, i1), ("C", c, c1), ("Z", z, z1)):
             if not torch.equal(x, y):
