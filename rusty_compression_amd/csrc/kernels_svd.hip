@@ -618,7 +618,8 @@ static void launch_lds_impl(rc_context *c, Mat<T> g, Mat<T> uc, T *s, Mat<T> vc,
         // on a context's first launch (epoch 0 until round 2) any small integer there passed for a sweep count or a sorted
         // position, and the consumer wrote V's columns to the wrong places without noticing (seen as one wrong `vt` among 16
         // contexts' first calls).  The epoch itself now starts at a per-context pseudo-random value (rc_context::epoch_word).
-        hipLaunchKernelGGL(k_clear_words, dim3(1), dim3(256), 0, c->stream, vsync, n + 1);
+        static const int no_clear = [] { const char *e = getenv("RC_DEBUG_JACOBI_NO_CLEAR"); return e ? atoi(e) : 0; }();  // (diagnostic: the round-2 behaviour)
+        if (!no_clear) hipLaunchKernelGGL(k_clear_words, dim3(1), dim3(256), 0, c->stream, vsync, n + 1);
         hipLaunchKernelGGL(kern, dim3(2), dim3(threads), lds, c->stream, g, log, sweeps, uc, s, order, max_sweeps, 1, vsync, chk, c->epoch_word(), vc, c->health_word(), ld);
     } else {
         hipLaunchKernelGGL(kern, dim3(1), dim3(threads), lds, c->stream, g, log, sweeps, uc, s, order, max_sweeps, 0, (unsigned *)nullptr, (unsigned long long *)nullptr,

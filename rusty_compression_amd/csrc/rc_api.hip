@@ -38,6 +38,20 @@ void rc_context::swap_arena() {
 }
 
 // the active arena (the fields of the context), whose users were issued on `st`
+// RC_DEBUG_POISON_WORKSPACE=1 (diagnostic, tests/test_gpu_parity.py): workspace memory that is new to a context is filled with
+// small integers (every 32-bit word = 3) before it is handed out -- what recycled allocator memory tends to look like.  Results
+// must not depend on it: this is how the fused Jacobi's uncleared hand-over words were pinned down.
+__global__ void k_poison_words(unsigned *p, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) p[i] = 3u;
+}
+static void poison_fresh(void *p, size_t bytes, hipStream_t st) {
+    static const bool on = [] { const char *e = getenv("RC_DEBUG_POISON_WORKSPACE"); return e && atoi(e) != 0; }();
+    if (!on || !p || bytes < 4) return;
+    static const bool verbose = [] { const char *e = getenv("RC_DEBUG_POISON_WORKSPACE"); return e && atoi(e) > 1; }();
+    if (verbose) fprintf(stderr, "poison %p %zu bytes\n", p, bytes);
+    hipLaunchKernelGGL(k_poison_words, dim3(1024), dim3(256), 0, st, static_cast<unsigned *>(p), bytes / 4);
+}
+
 static void reset_active_arena(rc_context *c, hipStream_t st) {
     if (!c->overflow.empty()) {
         // the previous call outgrew the arena: rebuild it once, big enough
@@ -46,7 +60,7 @@ static void reset_active_arena(rc_context *c, hipStream_t st) {
         c->overflow.clear();
         size_t want = c->arena_high + c->arena_high / 4 + (1u << 20);
         c->retire_arena();
-        if (hipMalloc(reinterpret_cast<void **>(&c->arena), want) == hipSuccess) c->arena_size = want;
+        if (hipMalloc(reinterpret_cast<void **>(&c->arena), want) == hipSuccess) { c->arena_size = want; poison_fresh(c->arena, want, st); }
     }
     c->arena_off = 0;
     c->arena_high = 0;
@@ -72,6 +86,7 @@ void *rc_context::alloc_bytes(size_t bytes) {
                    "workspace arena too small during hipGraph capture: run the same call once eagerly first (or rc_reserve_workspace)");
         RC_HIP(hipMalloc(&p, bytes));
         overflow.push_back(p);
+        poison_fresh(p, bytes, stream);
     }
     arena_off += bytes;
     arena_high = std::max(arena_high, arena_off);
@@ -84,6 +99,7 @@ void rc_context::reserve(size_t bytes) {
     retire_arena();
     RC_HIP(hipMalloc(reinterpret_cast<void **>(&arena), bytes));
     arena_size = bytes;
+    poison_fresh(arena, bytes, stream);
 }
 
 hipEvent_t rc_context::prof_event() {
@@ -128,6 +144,7 @@ unsigned *rc_context::epoch_word() {
                                        (unsigned long long)getpid() * 0xff51afd7ed558ccdull;
         unsigned e0 = (unsigned)(mix >> 29) & 0x7fffffu;  // 23 bits: far from the 24-bit wrap
         if (e0 == 0) e0 = 1;
+        if (const char *dbg = getenv("RC_DEBUG_EPOCH0")) e0 = (unsigned)atoi(dbg);  // (diagnostic: 0 = the round-2 behaviour)
         RC_HIP(hipMemcpy(epoch, &e0, sizeof(unsigned), hipMemcpyHostToDevice));
     }
     return epoch;

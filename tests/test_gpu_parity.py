@@ -1337,19 +1337,21 @@ def test_wide_coop_qrcp_many_streams_in_flight():
 
 
 def test_first_call_of_fresh_contexts_on_recycled_memory_matches_a_warm_context():
-    """The first call of a context runs on workspace memory the allocator hands out fresh -- here memory that was just released
-    full of small integers.  The fused Jacobi's tagged words (sweep count, sorted positions: "(epoch << 8) | payload") used to be
-    trusted uncleared, and a context's first epoch was 0: such integers passed for published values and V's columns went to the
-    wrong places (one wrong `vt` among 16 contexts' first calls at cfg3 size, nothing flagged).  Every fresh context must
-    reproduce the warm context's factors bit for bit."""
+    """The first call of a context runs on workspace memory the allocator hands out fresh -- here the blocks the previous
+    context (which worked on ANOTHER matrix) has just released, in the same roles.  The fused Jacobi's tagged words (sweep count,
+    sorted positions: "(epoch << 8) | payload") used to be trusted uncleared, and every context's first epoch was 0: the previous
+    context's words passed for this one's and V's columns went to the wrong places (one wrong `vt` among 16 contexts' first calls
+    at cfg3 size, nothing flagged).  Every fresh context must reproduce the warm context's factors bit for bit.  (What the
+    allocator hands out here is not under the test's control; the next test, with poisoned workspace, is the one that fails on the
+    old behaviour.)"""
     import ctypes
 
     from rusty_compression_amd import _lib
 
     m, n, k, p = 4096, 4096, 128, 5
-    a = rc.random_gaussian((m, n), rc.Rng(77), torch.float64)
+    mats = [rc.random_gaussian((m, n), rc.Rng(77 + j), torch.float64) for j in range(2)]
 
-    def run(ctx):
+    def run(ctx, a):
         mk = lambda r, c: torch.zeros((r, c), dtype=torch.float64, device="cuda")  # noqa: E731
         b = dict(range_q=mk(m, k), u=mk(m, k), s=torch.zeros(k, dtype=torch.float64, device="cuda"), vt=mk(k, n), qr_q=mk(m, k), qr_r=mk(k, n),
                  qr_ind=torch.zeros(n, dtype=torch.int64, device="cuda"), id_c=mk(m, k), id_z=mk(k, n))
@@ -1360,22 +1362,41 @@ def test_first_call_of_fresh_contexts_on_recycled_memory_matches_a_warm_context(
         return b
 
     warm = _lib.Context(torch.cuda.current_device(), torch.cuda.current_stream().cuda_stream)
-    run(warm)
-    want = run(warm)
-    an = npy(a)
-    assert rel((npy(want["u"]) * npy(want["s"])) @ npy(want["vt"]), npy(want["range_q"]) @ (npy(want["range_q"]).T @ an)) <= 1e-10
-    for i in range(10):
-        junk = [torch.full((64 << 20,), 1 + (i + j) % 200, dtype=torch.int32, device="cuda") for j in range(4)]  # 1 GiB of small integers
-        torch.cuda.synchronize()
-        del junk
-        torch.cuda.empty_cache()  # back to the driver: the library's next hipMalloc may get these pages
+    run(warm, mats[0])
+    want = [run(warm, a) for a in mats]
+    for a, w in zip(mats, want):
+        an, rq = npy(a), npy(w["range_q"])
+        assert rel((npy(w["u"]) * npy(w["s"])) @ npy(w["vt"]), rq @ (rq.T @ an)) <= 1e-10
+    for i in range(12):
         ctx = _lib.Context(torch.cuda.current_device(), torch.cuda.current_stream().cuda_stream)
-        got = run(ctx)
+        got = run(ctx, mats[i % 2])
         assert ctx.get_health() == 0
-        for f in want:
-            assert torch.equal(got[f], want[f]), f"fresh context {i}: {f} differs from the warm context's"
-        ctx.close()
+        for f in want[i % 2]:
+            assert torch.equal(got[f], want[i % 2][f]), f"fresh context {i}: {f} differs from the warm context's"
+        ctx.close()  # releases its workspace: the next context's first call gets these blocks
     warm.close()
+
+
+def test_results_do_not_depend_on_what_fresh_workspace_memory_holds():
+    """tests/poison_worker.py in two fresh processes, the second with RC_DEBUG_POISON_WORKSPACE=1 (workspace memory new to a context
+    is filled with small integers before it is handed out): every output digest must be the same.  With the round-2 behaviour of
+    the fused Jacobi (RC_DEBUG_JACOBI_NO_CLEAR=1 RC_DEBUG_EPOCH0=0) the poisoned run differs in the SVD outputs."""
+    import json
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+    def digests(extra):
+        env = dict(os.environ, **extra)
+        res = subprocess.run([sys.executable, os.path.join(root, "tests", "poison_worker.py")], env=env, capture_output=True, text=True, timeout=600)
+        assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-2000:]
+        line = [ln for ln in res.stdout.splitlines() if ln.startswith("DIGESTS ")][-1]
+        return json.loads(line[len("DIGESTS "):])
+
+    plain, poisoned = digests({"RC_DEBUG_POISON_WORKSPACE": "0"}), digests({"RC_DEBUG_POISON_WORKSPACE": "1"})
+    assert plain.keys() == poisoned.keys() and len(plain) >= 9
+    assert plain == poisoned, {k: (plain[k], poisoned[k]) for k in plain if plain[k] != poisoned[k]}
 
 
 def test_cpp_mirror_runs_the_reference_examples(tmp_path):
