@@ -1382,6 +1382,7 @@ def test_results_do_not_depend_on_what_fresh_workspace_memory_holds():
     is filled with small integers before it is handed out): every output digest must be the same.  With the round-2 behaviour of
     the fused Jacobi (RC_DEBUG_JACOBI_NO_CLEAR=1 RC_DEBUG_EPOCH0=0) the poisoned run differs in the SVD outputs."""
     import json
+    import os
     import subprocess
     import sys
 
