@@ -41,15 +41,17 @@ void rc_context::swap_arena() {
 // RC_DEBUG_POISON_WORKSPACE=1 (diagnostic, tests/test_gpu_parity.py): workspace memory that is new to a context is filled with
 // small integers (every 32-bit word = 3) before it is handed out -- what recycled allocator memory tends to look like.  Results
 // must not depend on it: this is how the fused Jacobi's uncleared hand-over words were pinned down.
-__global__ void k_poison_words(unsigned *p, size_t n) {
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) p[i] = 3u;
+__global__ void k_poison_words(unsigned *p, size_t n, unsigned v) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) p[i] = v;
 }
 static void poison_fresh(void *p, size_t bytes, hipStream_t st) {
     static const bool on = [] { const char *e = getenv("RC_DEBUG_POISON_WORKSPACE"); return e && atoi(e) != 0; }();
     if (!on || !p || bytes < 4) return;
     static const bool verbose = [] { const char *e = getenv("RC_DEBUG_POISON_WORKSPACE"); return e && atoi(e) > 1; }();
     if (verbose) fprintf(stderr, "poison %p %zu bytes\n", p, bytes);
-    hipLaunchKernelGGL(k_poison_words, dim3(1024), dim3(256), 0, st, static_cast<unsigned *>(p), bytes / 4);
+    // 1 (2: verbose): every word 3; 3: every word 0xffffffff (a NaN in f32 and f64, -1 as an index)
+    static const unsigned value = [] { const char *e = getenv("RC_DEBUG_POISON_WORKSPACE"); return e && atoi(e) == 3 ? 0xffffffffu : 3u; }();
+    hipLaunchKernelGGL(k_poison_words, dim3(1024), dim3(256), 0, st, static_cast<unsigned *>(p), bytes / 4, value);
 }
 
 static void reset_active_arena(rc_context *c, hipStream_t st) {
