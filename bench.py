@@ -124,6 +124,10 @@ def main():
         import torch.distributed as dist  # noqa: F811
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if world == 1:  # forced single-rank run outside torchrun: the rendezvous variables torchrun would have set
+            os.environ.setdefault("RANK", "0")
+            os.environ.setdefault("WORLD_SIZE", "1")
+            os.environ.setdefault("MASTER_PORT", "29533")
         if rehearsal:
             dist.init_process_group(backend="gloo")
         else:
