@@ -175,6 +175,8 @@ def main():
                 ctx.set_option(_lib.RC_OPT_CONCURRENCY_HINT, S)  # S compressions in flight: wide GEMMs stay un-split (no partial slabs)
             call()  # eager warm-up: sizes the workspace arena (required before capture)
             ctx.synchronize()
+            # what the replays of the timed region must reproduce bit for bit (checked after it): singular values and pivots
+            eager_ref = (bufs["s"].clone(), bufs["qr_ind"].clone() if with_id else None)
             graph = ctypes.c_void_p(None)
             if not args.no_graph:
                 ctx.check(_lib.lib().rc_graph_begin_capture(ctx._h))
@@ -184,7 +186,7 @@ def main():
                 # small --warmup does not leave first launches inside the timed region
                 ctx.check(_lib.lib().rc_graph_launch(ctx._h, graph))
                 ctx.synchronize()
-            lanes.append(dict(stream=st, ctx=ctx, a=a, bufs=bufs, out=out, call=call, graph=graph))
+            lanes.append(dict(stream=st, ctx=ctx, a=a, bufs=bufs, out=out, call=call, graph=graph, eager_ref=eager_ref))
 
     lane_events = []
 
@@ -281,6 +283,8 @@ def main():
     # every captured tall-skinny fast path must have certified itself (no fallback exists inside a graph)
     health = [ln["ctx"].get_health() for ln in lanes]
     assert not any(health), f"fast-path certificate failed during the timed region: {health}"
+    # the last compression of every lane (a graph replay under full concurrency) against that lane's eager warm-up result
+    replay_ok = sum(1 for ln in lanes if torch.equal(ln["bufs"]["s"], ln["eager_ref"][0]) and (ln["eager_ref"][1] is None or torch.equal(ln["bufs"]["qr_ind"], ln["eager_ref"][1])))
     elapsed = t1 - t0
     if dist is not None:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if rehearsal else "cuda")
@@ -477,6 +481,7 @@ def main():
             "cpu_baseline_gemm_form": cpu_gemm,
             "value_including_h2d": h2d,
             "stage_ms_single_stream_eager": stage_ms,
+            "timed_results_check": {"lanes_whose_last_replay_equals_their_eager_result_bitwise": replay_ok, "lanes": S, "compared": "singular values + pivot vector"},
         }
         _emit(json.dumps(line))
 
