@@ -8,7 +8,9 @@ Workload (BASELINE.json configs[2], the one `metric` is quoted on; it fits one G
                            -> QR::compute_from_range_estimate -> column_id
   with A resident in HBM and Omega generated on the device.
 
-  python bench.py --gpus N --steps K --warmup W      (N > 1: launched by torch.distributed.run)
+  python bench.py --gpus N --steps K --warmup W      (N > 1: under torch.distributed.run, or alone -- bench.py then starts
+                                                      its N ranks itself, see launch_ranks)
+  python bench.py --config cfg5 [--gpus N]           BASELINE.json configs[4]: the sharded batch of column IDs + factor gather
 
 Independent matrices are the unit of parallelism: every rank
 compresses its own matrices (weak scaling, no data-path collective); within a rank
@@ -60,6 +62,20 @@ def work_model(m, n, k, p, with_id=True):
     return fl, by
 
 
+def host_threads():
+    """Threads the oracle's BLAS / LAPACK (SciPy's OpenBLAS) runs on, and where that number comes from."""
+    try:
+        from threadpoolctl import threadpool_info
+
+        pools = [(int(x.get("num_threads", 1)), x.get("internal_api", "?")) for x in threadpool_info()]
+        if pools:
+            nthr, api = max(pools)
+            return nthr, "threadpoolctl (%s pool)" % api
+    except Exception:
+        pass
+    return os.cpu_count() or 1, "os.cpu_count()"
+
+
 # The contract is ONE JSON line on stdout.  Libraries below us write there too (RCCL prints a version banner at communicator
 # creation), so the process's fd 1 is pointed at stderr for the whole run and the line goes to the original stdout.
 _REAL_STDOUT = None
@@ -78,33 +94,140 @@ def _emit(text):
     os.write(_REAL_STDOUT if _REAL_STDOUT is not None else 1, (text + "\n").encode())
 
 
-def main():
-    _guard_stdout()
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=12, help="timed rounds; one round = one compression on each lane")
+    ap.add_argument("--steps", type=int, default=12, help="timed rounds; one round = one compression on each lane (cfg3) / one batch per GPU (cfg5)")
     ap.add_argument("--warmup", type=int, default=2, help="untimed rounds")
+    ap.add_argument("--config", choices=("cfg3", "cfg5"), default="cfg3",
+                    help="cfg3 (default, the headline): 8192^2 f64 rank-128 rSVD+ID, independent matrices per GPU.  cfg5: BASELINE.json configs[4], "
+                         "4096^2 f32 rank-64 column ID, --matrices-per-gpu (8) per rank through rc_batch_column_id_f32 + the factor gather to rank 0")
     ap.add_argument("--streams", type=int, default=42, help="independent compressions in flight per GPU")
-    ap.add_argument("--size", type=int, default=8192)
-    ap.add_argument("--rank", type=int, default=128)
+    ap.add_argument("--size", type=int, default=None, help="matrix size (cfg3: 8192, cfg5: 4096)")
+    ap.add_argument("--rank", type=int, default=None, help="target rank (cfg3: 128, cfg5: 64)")
     ap.add_argument("--oversample", type=int, default=5)
+    ap.add_argument("--matrices-per-gpu", type=int, default=8, help="cfg5: matrices of the batch held by each rank (weak scaling: 8 N in total)")
+    ap.add_argument("--batch-lanes", type=int, default=8, help="cfg5: contexts / streams the batch call spreads its matrices over")
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying hipGraphs")
     ap.add_argument("--no-id", action="store_true", help="rSVD only (skip QR-from-range + column ID)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-baseline-reps", type=int, default=2, help="compressions timed on the host (about 5 s each on the GPU box)")
     ap.add_argument("--no-concurrency-hint", action="store_true", help="leave RC_OPT_CONCURRENCY_HINT at 1 (every GEMM splits K for a lone launch)")
     ap.add_argument("--no-h2d", action="store_true", help="skip the second throughput figure that re-uploads A before every compression")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="launcher / rendezvous rehearsal WITHOUT a GPU: ranks meet over gloo, run barriers and the MAX reduction around sleeps; "
+                         "the line carries value null and dry_run true -- never a measurement (tests/test_dist_cpu.py)")
     ap.add_argument("--lane-events", action="store_true",
                     help="diagnostic: HIP events around every timed step on its lane's stream; start/end offsets go to stderr")
     ap.add_argument("--profile-concurrent", action="store_true",
                     help="diagnostic: per-stage HIP-event timers with ALL streams busy (eager launches), printed to stderr")
-    args = ap.parse_args()
+    return ap.parse_args(argv)
 
-    import numpy as np
+
+def _free_port():
+    import socket
+
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def launch_ranks(args, argv):
+    """`python bench.py --gpus N` outside a launcher (no WORLD_SIZE in the environment): this process starts the N ranks itself,
+    as plain child processes with the rendezvous variables torch.distributed.run would set, forwards rank 0's single JSON line and
+    exits with the worst child status.  It never imports torch and never touches the GPU (and nothing here replaces a process:
+    children are started with Popen).  Returns the exit status."""
+    import subprocess
+    import threading
+
+    n = args.gpus
+    env0 = dict(os.environ)
+    env0.setdefault("MASTER_ADDR", "127.0.0.1")
+    env0["MASTER_PORT"] = str(_free_port())
+    env0["WORLD_SIZE"] = env0["LOCAL_WORLD_SIZE"] = str(n)
+    env0.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, os.path.abspath(__file__)] + list(argv)
+    procs = []
+    for r in range(n):
+        env = dict(env0, RANK=str(r), LOCAL_RANK=str(r), GROUP_RANK="0")
+        # rank 0's stdout carries the line; whatever another rank writes to its stdout is diagnostics
+        procs.append(subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE if r == 0 else sys.stderr, stderr=None))
+    captured = []
+    reader = threading.Thread(target=lambda: captured.append(procs[0].stdout.read()), daemon=True)
+    reader.start()
+    deadline = time.time() + float(os.environ.get("RC_BENCH_LAUNCH_TIMEOUT", "1500"))
+    first_failure = None
+    while any(p.poll() is None for p in procs):
+        time.sleep(0.2)
+        bad = [p for p in procs if p.poll() not in (None, 0)]
+        if bad and first_failure is None:
+            first_failure = time.time()  # the others would wait at the rendezvous / a barrier for ever: give them a moment, then end them
+        if (first_failure is not None and time.time() - first_failure > 5.0) or time.time() > deadline:
+            for p in procs:
+                if p.poll() is None:
+                    p.terminate()   # exactly the processes started above
+            t_kill = time.time() + 10.0
+            while any(p.poll() is None for p in procs) and time.time() < t_kill:
+                time.sleep(0.1)
+            for p in procs:
+                if p.poll() is None:
+                    p.kill()
+    reader.join(timeout=10.0)
+    codes = [p.wait() for p in procs]
+    own = [c for c in codes if c > 0]   # a rank's own failure status ranks above the signal this launcher ended its peers with
+    worst = max(own) if own else max((128 - c if c < 0 else 0) for c in codes)
+    text = (captured[0] if captured else b"").decode(errors="replace")
+    lines = [ln for ln in text.splitlines() if ln.strip().startswith("{")]
+    if worst == 0 and len(lines) != 1:
+        print("bench.py launcher: rank 0 printed %d JSON lines, expected 1" % len(lines), file=sys.stderr)
+        worst = 1
+    if worst == 0:
+        rec = json.loads(lines[0])
+        if rec.get("n_gpus") != n:
+            print("bench.py launcher: rank 0 reports n_gpus=%r, %d ranks were started" % (rec.get("n_gpus"), n), file=sys.stderr)
+            worst = 1
+        else:
+            _emit(lines[0])
+    else:
+        print("bench.py launcher: rank exit codes %s" % codes, file=sys.stderr)
+    return worst
+
+
+def run_dry(args):
+    """Rendezvous / barrier / MAX-over-ranks / one-line path of an N-rank run with the compute replaced by sleeps (no GPU needed;
+    the CPU suite starts `bench.py --gpus 2 --dry-run` and checks that the launcher produced two ranks)."""
     import torch
+    import torch.distributed as dist
 
-    import rusty_compression_amd as rc
-    from rusty_compression_amd import _lib
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    if os.environ.get("RC_BENCH_DRY_FAIL_RANK") == str(rank):
+        raise SystemExit(3)   # test hook: a rank that dies before the rendezvous
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="gloo")
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        time.sleep(0.01 * (rank + 1))
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        dist.barrier()
+        t = torch.tensor([elapsed], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+        dist.destroy_process_group()
+    if rank == 0:
+        _emit(json.dumps({"metric": "dry run of the launcher -- not a measurement", "value": None, "unit": None, "n_gpus": world, "steps": args.steps,
+                          "warmup": args.warmup, "ms_per_step": round(elapsed / max(args.steps, 1) * 1e3, 3), "dry_run": True, "data": "none",
+                          "config": {"workload": "%s launcher rehearsal, no GPU work" % args.config}}))
+
+
+def setup_ranks(args):
+    """Device selection + process group of a (possibly multi-rank) GPU run.  Returns (torch, dist or None, world, rank, local_rank, rehearsal)."""
+    import torch
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -116,6 +239,8 @@ def main():
     rehearsal = os.environ.get("RC_BENCH_REHEARSAL", "0") == "1"
     if rehearsal:
         local_rank = 0
+    if local_rank >= torch.cuda.device_count():
+        raise SystemExit("bench.py: rank %d wants GPU %d, this node shows %d (use --gpus <= the node's GPU count)" % (rank, local_rank, torch.cuda.device_count()))
     torch.cuda.set_device(local_rank)
     dist = None
     # RC_BENCH_FORCE_DIST=1 (never set by the driver): take the N > 1 code path -- RCCL init, barriers, MAX all-reduce on a device
@@ -132,7 +257,33 @@ def main():
             dist.init_process_group(backend="gloo")
         else:
             dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+    return torch, dist, world, rank, local_rank, rehearsal
 
+
+def main(argv=None):
+    argv = list(sys.argv[1:] if argv is None else argv)
+    args = parse_args(argv)
+    _guard_stdout()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # the driver may start `python bench.py --gpus N` exactly as it starts `--gpus 1`: be the launcher, before torch or
+        # the GPU is touched in this process
+        raise SystemExit(launch_ranks(args, argv))
+    if args.dry_run:
+        return run_dry(args)
+    if args.config == "cfg5":
+        return run_cfg5(args)
+    return run_cfg3(args)
+
+
+def run_cfg3(args):
+    import numpy as np
+
+    torch, dist, world, rank, local_rank, rehearsal = setup_ranks(args)
+    import rusty_compression_amd as rc
+    from rusty_compression_amd import _lib
+
+    args.size = args.size or 8192
+    args.rank = args.rank or 128
     m = n = args.size
     k, p = args.rank, args.oversample
     l = k + p
@@ -175,8 +326,8 @@ def main():
                 ctx.set_option(_lib.RC_OPT_CONCURRENCY_HINT, S)  # S compressions in flight: wide GEMMs stay un-split (no partial slabs)
             call()  # eager warm-up: sizes the workspace arena (required before capture)
             ctx.synchronize()
-            # what the replays of the timed region must reproduce bit for bit (checked after it): singular values and pivots
-            eager_ref = (bufs["s"].clone(), bufs["qr_ind"].clone() if with_id else None)
+            # what the replays of the timed region must reproduce bit for bit (checked after it): EVERY output buffer
+            eager_ref = {name: t.clone() for name, t in bufs.items()}
             graph = ctypes.c_void_p(None)
             if not args.no_graph:
                 ctx.check(_lib.lib().rc_graph_begin_capture(ctx._h))
@@ -283,8 +434,16 @@ def main():
     # every captured tall-skinny fast path must have certified itself (no fallback exists inside a graph)
     health = [ln["ctx"].get_health() for ln in lanes]
     assert not any(health), f"fast-path certificate failed during the timed region: {health}"
-    # the last compression of every lane (a graph replay under full concurrency) against that lane's eager warm-up result
-    replay_ok = sum(1 for ln in lanes if torch.equal(ln["bufs"]["s"], ln["eager_ref"][0]) and (ln["eager_ref"][1] is None or torch.equal(ln["bufs"]["qr_ind"], ln["eager_ref"][1])))
+    # the last compression of every lane (a graph replay under full concurrency) against that lane's eager warm-up result:
+    # every output buffer (range_q, u, s, vt, qr_q, qr_r, qr_ind, id_c, id_z), bit for bit
+    replay_bad = {}
+    for i, ln in enumerate(lanes):
+        diff = [name for name, t in ln["bufs"].items() if not torch.equal(t, ln["eager_ref"][name])]
+        if diff:
+            replay_bad[i] = diff
+    replay_ok = S - len(replay_bad)
+    for ln in lanes:
+        ln["eager_ref"] = None   # 2.4 GB of copies back to the allocator
     elapsed = t1 - t0
     if dist is not None:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if rehearsal else "cuda")
@@ -424,12 +583,7 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         from oracle import ref_lapack as o
 
-        try:
-            from threadpoolctl import threadpool_info
-
-            cores = max([int(x.get("num_threads", 1)) for x in threadpool_info()] or [1])
-        except Exception:
-            cores = os.cpu_count() or 1
+        cores, cores_source = host_threads()
         a_h = lanes[0]["a"].cpu().numpy()
         om_h = np.random.default_rng(0).standard_normal((n, l))
         tc0 = time.perf_counter()
@@ -439,11 +593,11 @@ def main():
         tg0 = time.perf_counter()
         o.rsvd_id_reference_shape(a_h, om_h, k, faithful=False)
         tg = time.perf_counter() - tg0
-        cpu_gemm = {"value": round(1.0 / tg, 4), "unit": "compressions/s", "cores": cores, "kind": "port",
+        cpu_gemm = {"value": round(1.0 / tg, 4), "unit": "compressions/s", "cores": cores, "cores_source": cores_source, "kind": "port",
                     "sample": "1 compression of the same matrix with the two operator products as single GEMMs (numpy @ / OpenBLAS dgemm) "
                               "instead of the reference's per-column gemv loops; everything else as cpu_baseline; %.2f s" % tg,
                     "seconds_per_compression": round(tg, 3)}
-        cpu = {"value": round(1.0 / tc, 4), "unit": "compressions/s", "cores": cores, "kind": "port",
+        cpu = {"value": round(1.0 / tc, 4), "unit": "compressions/s", "cores": cores, "cores_source": cores_source, "kind": "port",
                "sample": "%d compression(s) of the same 8192x8192 f64 matrix, rSVD+ID, reference call shape "
                          "(per-column gemv loops for A*Omega and A^H*Q, ?geqp3+?orgqr, ?gesdd, per-column ?trtrs) via oracle/ref_lapack.py "
                          "(SciPy LAPACK/OpenBLAS), %.2f s each" % (args.cpu_baseline_reps, tc),
@@ -481,8 +635,12 @@ def main():
             "cpu_baseline_gemm_form": cpu_gemm,
             "value_including_h2d": h2d,
             "stage_ms_single_stream_eager": stage_ms,
-            "timed_results_check": {"lanes_whose_last_replay_equals_their_eager_result_bitwise": replay_ok, "lanes": S, "compared": "singular values + pivot vector"},
+            "timed_results_check": {"lanes_whose_last_replay_equals_their_eager_result_bitwise": replay_ok, "lanes": S,
+                                    "compared": "every output buffer: " + ", ".join(sorted(lanes[0]["bufs"])),
+                                    "lanes_that_differ": {str(i): v for i, v in sorted(replay_bad.items())}},
         }
+        if replay_ok != S:
+            line["invalid"] = "the timed replays of %d lane(s) did not reproduce their eager result" % (S - replay_ok)
         _emit(json.dumps(line))
 
     for ln in lanes:
@@ -490,6 +648,161 @@ def main():
             _lib.lib().rc_graph_destroy(ln["ctx"]._h, ln["graph"])
     if dist is not None:
         dist.destroy_process_group()
+    if replay_ok != S:
+        print("bench.py: timed_results_check FAILED on rank %d: %s" % (rank, replay_bad), file=sys.stderr)
+        raise SystemExit(4)
+
+
+
+F32_MFMA_PEAK_TFLOPS = 157.3  # MI355X f32 matrix peak (vendor datasheet value)
+
+
+def run_cfg5(args):
+    """BASELINE.json configs[4]: a batch of independent 4096 x 4096 f32 matrices, rank-64 column ID
+    (QR::compute_from -> compress(RANK(k)) -> column_id, examples/interpolative_decomposition.rs:25-32), sharded by matrix
+    (rc_batch_shard_range: 8 per GPU, 64 on 8 GPUs -- weak scaling), each rank's share through ONE rc_batch_column_id_f32 call,
+    then the ONLY collective of the path: the gather of the packed factor blocks to rank 0 (rc_comm_gather, RCCL over xGMI).
+    One STEP = one such batch + gather on every rank; value = matrices/s over all ranks."""
+    import numpy as np
+
+    torch, dist, world, rank, local_rank, rehearsal = setup_ranks(args)
+    import rusty_compression_amd as rc
+    from rusty_compression_amd import _lib, batch
+
+    m = n = args.size or 4096
+    k = args.rank or 64
+    nloc = max(1, args.matrices_per_gpu)
+    total = nloc * world
+    start, count = ctypes.c_int64(0), ctypes.c_int64(0)
+    assert _lib.lib().rc_batch_shard_range(ctypes.c_int64(total), ctypes.c_int32(world), ctypes.c_int32(rank), ctypes.byref(start), ctypes.byref(count)) == 0
+    mine = list(range(start.value, start.value + count.value))
+    assert len(mine) == nloc
+    mats = [rc.random_gaussian((m, n), rc.Rng(500 + i), torch.float32) for i in mine]   # SURVEY.md 8(d): seeds 500..563
+    torch.cuda.synchronize()
+    per = batch.packed_bytes(m, n, k, 4)
+    comm = None
+    if dist is not None and world > 1 and not rehearsal:
+        comm = batch.Comm.from_process_group(None, local_rank)
+    elif os.environ.get("RC_BENCH_FORCE_DIST", "0") == "1" and world == 1:
+        comm = batch.Comm(1, 0, batch.Comm.unique_id(), local_rank)   # one-rank RCCL communicator: the entry points themselves
+
+    gather_s = []
+
+    def gather(packed):
+        t0 = time.perf_counter()
+        if comm is not None:
+            got = comm.gather(packed, 0)   # grouped ncclSend / ncclRecv on the context's stream + rc_synchronize
+        elif dist is not None and world > 1:  # rehearsal: all ranks on one device, gloo on host copies
+            src = packed.cpu()
+            parts = [torch.empty_like(src) for _ in range(world)] if rank == 0 else None
+            dist.gather(src, parts, dst=0)
+            got = torch.cat(parts).to(packed.device) if rank == 0 else None
+        else:
+            got = packed
+        gather_s.append(time.perf_counter() - t0)
+        return got
+
+    def step():
+        packed = batch.batch_column_id_packed(mats, k, lanes=args.batch_lanes)
+        return gather(packed)
+
+    first = step()
+    first = first.clone() if first is not None else None
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    gather_s.clear()
+    t0 = time.perf_counter()
+    last = None
+    for _ in range(args.steps):
+        last = step()
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    if dist is not None:
+        dist.barrier()
+    elapsed = t1 - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if rehearsal else "cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # ---- what was timed is checked on rank 0: the last gathered batch equals the first bit for bit, and every matrix of every rank
+    # satisfies the ID's defining identities against the matrix regenerated from its seed -------------------------------------------
+    check = None
+    bad = []
+    if rank == 0:
+        same = bool(torch.equal(first, last))
+        facs = batch.unpack_factors(last, total, m, n, k, torch.float32)
+        for i, (c, z, ind) in enumerate(facs):
+            a = mats[i - mine[0]] if mine[0] <= i < mine[0] + nloc else rc.random_gaussian((m, n), rc.Rng(500 + i), torch.float32)
+            is_perm = bool(torch.equal(torch.sort(ind).values, torch.arange(n, device=ind.device)))
+            if not is_perm:
+                bad.append((i, "col_ind is not a permutation"))
+                continue
+            sel = a[:, ind[:k]]
+            e_c = float((c - sel).norm() / sel.norm())
+            e_i = float((z[:, ind[:k]] - torch.eye(k, dtype=z.dtype, device=z.device)).abs().max())
+            if not (e_c <= 1e-4 and e_i <= 1e-5):
+                bad.append((i, "C vs A[:, col_ind[:k]] %.2e, Z[:, col_ind[:k]] vs I %.2e" % (e_c, e_i)))
+        check = {"matrices_checked": total, "identities": "col_ind a permutation; C = A[:, col_ind[:k]] (rel. Frobenius <= 1e-4); Z[:, col_ind[:k]] = I (<= 1e-5)",
+                 "failed": [list(b) for b in bad], "last_timed_batch_equals_first_bitwise": same}
+        if not same:
+            bad.append((-1, "the last timed batch differs from the first one"))
+
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        from oracle import ref_lapack as o
+
+        cores, cores_source = host_threads()
+        a_h = mats[0].cpu().numpy()
+        tc0 = time.perf_counter()
+        o.QR.compute_from(a_h).compress("RANK", k).column_id()
+        tc = time.perf_counter() - tc0
+        cpu = {"value": round(1.0 / tc, 4), "unit": "matrices/s", "cores": cores, "cores_source": cores_source, "kind": "port",
+               "sample": "1 matrix of the batch, reference call sequence QR::compute_from (full sgeqp3 + sorgqr of 4096 x 4096) -> compress(RANK(64)) -> "
+                         "column_id (per-column strtrs) via oracle/ref_lapack.py (SciPy LAPACK/OpenBLAS), %.2f s" % tc,
+               "seconds_per_matrix": round(tc, 3)}
+
+    if rank == 0:
+        n_mat = args.steps * total
+        value = n_mat / elapsed
+        flops = 4.0 * m * n * k - 2.0 * (m + n) * k * k + (4.0 / 3.0) * k ** 3 + 1.0 * k * k * (n - k)   # SURVEY.md 8(d): truncated QRCP + TRSM
+        by = 4.0 * m * n + 4.0 * (m * k + k * n) + 8.0 * n                                              # A once + C, Z, col_ind
+        g_ms = sorted(x * 1e3 for x in gather_s)
+        line = {
+            "metric": "matrices/sec, batch of 4096x4096 f32 rank-64 column ID, 8 per GPU + RCCL gather of the factors",
+            "value": round(value, 2), "unit": "matrices/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "cfg5: batch of %d independent %dx%d f32 dense N(0,1) matrices (seeds 500..%d), rank-%d column ID, %d per GPU "
+                                   "(BASELINE.json configs[4])" % (total, m, n, 499 + total, k, nloc),
+                       "matrices_per_step": total, "matrices_timed": n_mat, "batch_lanes": args.batch_lanes,
+                       "parallelism": "independent matrices, rc_batch_shard_range; gather: %s" % (
+                           "rc_comm_gather (RCCL)" if comm is not None else ("gloo on host copies (rehearsal)" if world > 1 else "single rank, none"))},
+            "gather_ms_median": round(g_ms[len(g_ms) // 2], 4) if g_ms else None,
+            "gather_bytes_per_rank": nloc * per,
+            "gb_per_s": round(value * by / 1e9, 2),
+            "tflops_algorithmic": round(value * flops / 1e12, 3),
+            "frac_of_f32_mfma_peak_whole_pipeline": round(value * flops / 1e12 / (F32_MFMA_PEAK_TFLOPS * world), 4),
+            "bytes_per_matrix": by, "flops_per_matrix": flops,
+            "roofline": {"bound": "hbm", "kernel": "rc_batch_column_id_f32 (the whole batch call; its kernels are latency-bound pivot panels + streaming panel ends)",
+                         "achieved": round(value / world * by / 1e9, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(value / world * by / 1e9 / HBM_PEAK_GBS, 5),
+                         "traffic": None, "method": "algorithmic bytes per matrix x matrices per second per GPU (host clock around the timed region)"},
+            "cpu_baseline": cpu,
+            "timed_results_check": check,
+        }
+        if bad:
+            line["invalid"] = "result check failed: %s" % bad
+        _emit(json.dumps(line))
+    if comm is not None:
+        comm.close()
+    if dist is not None:
+        dist.destroy_process_group()
+    if bad:
+        raise SystemExit(4)
 
 
 if __name__ == "__main__":

@@ -137,6 +137,22 @@ class Comm:
         if st != 0:
             raise _lib.HipRuntimeError(f"rc_comm_init failed with status {st}")
 
+    @classmethod
+    def from_process_group(cls, group=None, device: Optional[int] = None) -> "Comm":
+        """The library's RCCL communicator for the ranks of a torch.distributed group: rank 0 draws the unique id
+        (rc_comm_unique_id) and the group carries its 128 bytes to the others once; every later byte moves through rc_comm_gather."""
+        import torch.distributed as dist
+
+        world, rank = dist.get_world_size(group), dist.get_rank(group)
+        dev = torch.cuda.current_device() if device is None else int(device)
+        ident = torch.zeros(128, dtype=torch.uint8)
+        if rank == 0:
+            ident = torch.frombuffer(bytearray(cls.unique_id()), dtype=torch.uint8).clone()
+        if dist.get_backend(group) == "nccl":
+            ident = ident.cuda(dev)
+        dist.broadcast(ident, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+        return cls(world, rank, bytes(ident.cpu().numpy().tobytes()), dev)
+
     @staticmethod
     def unique_id() -> bytes:
         from . import _lib

@@ -98,8 +98,15 @@ void batch_column_id(rc_context *const *ctxs, int nctx, const rc_matrix *mats, i
     std::vector<Lane> lanes((size_t)nctx);
     struct Cleanup {
         std::vector<Lane> &l;
-        ~Cleanup() { for (auto &x : l) if (x.job) { qrb_end(x.job); x.job = nullptr; } }
-    } cleanup{lanes};
+        rc_context *const *ctxs;
+        int nctx;
+        // every lane is quiescent before the jobs go and before the call returns -- also when it unwinds on an error: with several
+        // issuing threads ANY lane may hold the last matrices' work, and the caller frees `packed` and reuses the arenas afterwards
+        ~Cleanup() {
+            (void)rc_synchronize_all(ctxs, (int32_t)nctx);
+            for (auto &x : l) if (x.job) { qrb_end(x.job); x.job = nullptr; }
+        }
+    } cleanup{lanes, ctxs, nctx};
     auto slot = [&](int idx) { return static_cast<char *>(packed) + (size_t)idx * per; };
     // RC_BATCH_LOCKSTEP_THREADS=1 (lock-step schedule only): one host thread per lane for the issue phases (measured slower than inline issue once the panels
     // replay from hipGraphs: thread start-up + runtime locks cost more than the launches they overlap)
@@ -250,7 +257,7 @@ void batch_column_id(rc_context *const *ctxs, int nctx, const rc_matrix *mats, i
                 if (e.code != RC_OK) throw e;
         }
     }
-    std::vector<rc_context *> all(ctxs, ctxs + std::min(nctx, count));
+    std::vector<rc_context *> all(ctxs, ctxs + nctx);  // all of them: which lanes were handed matrices depends on the issuing threads
     RC_REQUIRE(rc_synchronize_all(all.data(), (int32_t)all.size()) == RC_OK, RC_RUNTIME_ERROR, "batch_column_id: wait failed");
     for (rc_context *c : all) {
         hipError_t e = hipGetLastError();

@@ -143,8 +143,8 @@ def sample_range_by_rank_sharded(a_local, k: int, p: int, seed: int, group=None,
     a = ops.prepare(a_local)
     m_r, n = a.shape
     l = k + p
-    assert m_r >= l, f"every rank needs at least k + p = {l} rows, this one has {m_r}"
     world, rank, _ = _world(group)
+    _agree_on_shapes(m_r, n, l, group)
     omega = ops.random_gaussian((n, l), seed, a)         # the same stream on every rank
     y = ops.matmat(a, omega)                             # m_r x l
     q_r, r_r, ind_r = ops.pivoted_qr(y)                  # Y_r[:, ind_r] = Q_r R_r
@@ -155,6 +155,25 @@ def sample_range_by_rank_sharded(a_local, k: int, p: int, seed: int, group=None,
     q_s, _, _ = ops.pivoted_qr(s_all)                    # (W l) x l, identical on every rank
     block = q_s[rank * l:(rank + 1) * l, :min(k, l)].contiguous()
     return ops.dot(q_r, block)                           # m_r x k
+
+
+def _agree_on_shapes(m_r: int, n: int, l: int, group=None) -> None:
+    """The precondition of the sharded calls (every rank holds >= k + p rows, all ranks the same column count) is checked
+    COLLECTIVELY before the first data collective: a rank that fails alone would raise while its peers block in the all-gather
+    (for ever on RCCL).  One all-reduce of three integers; every rank raises the same AssertionError or none does.
+    A failing host callback / compute step on one rank later on still strands the others: the group has to be torn down then."""
+    world, _, dist = _world(group)
+    ok = m_r >= l
+    if world > 1:
+        t = torch.tensor([1 if ok else 0, n, -n], dtype=torch.int64)
+        if not _host_staged(dist, group):
+            t = t.cuda()
+        dist.all_reduce(t, op=dist.ReduceOp.MIN, group=group)
+        all_ok, n_min, n_max = int(t[0]), int(t[1]), -int(t[2])
+        assert n_min == n_max, f"the row blocks disagree on the column count ({n_min} .. {n_max})"
+        assert all_ok == 1, f"every rank needs at least k + p = {l} rows" + ("" if ok else f", this one has {m_r}")
+    else:
+        assert ok, f"every rank needs at least k + p = {l} rows, this one has {m_r}"
 
 
 _GATHER_FN = ctypes.CFUNCTYPE(ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t)
@@ -244,7 +263,7 @@ def _rsvd_id_row_sharded_native(a_local, k: int, p: int, seed: int, group, with_
 
     a = as_device(a_local)
     m_r, n = a.shape
-    assert m_r >= k + p, f"every rank needs at least k + p = {k + p} rows, this one has {m_r}"
+    _agree_on_shapes(m_r, n, k + p, group)
     comm = communicator(group)
     mk = lambda r, c: torch.empty((r, c), dtype=a.dtype, device=a.device)  # noqa: E731
     rq, u, vt = mk(m_r, k), mk(m_r, k), mk(k, n)
