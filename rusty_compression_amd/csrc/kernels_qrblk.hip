@@ -1327,8 +1327,8 @@ BlockedQrcpJob<T> *qrb_begin(rc_context *c, Mat<T> w, int64_t kmax, int64_t *jpv
         c->pinned_size = 1 << 16;
     }
     J->host_st = reinterpret_cast<QrbState *>(c->pinned);
-    RC_HIP(hipMemsetAsync(J->Fm, 0, (size_t)n * kNB * sizeof(T), c->stream));  // whole F rows are read: keep them finite
-    RC_HIP(hipMemsetAsync(J->Tm, 0, (size_t)kNB * kNB * sizeof(T), c->stream));  // strictly lower part of T stays zero (block form-Q multiplies by the full square)
+    fill_words(c, J->Fm, (size_t)n * kNB * sizeof(T), 0u);  // whole F rows are read: keep them finite
+    fill_words(c, J->Tm, (size_t)kNB * kNB * sizeof(T), 0u);  // strictly lower part of T stays zero (block form-Q multiplies by the full square)
     J->vec_ok = (w.cs % (16 / (int64_t)sizeof(T)) == 0 && reinterpret_cast<uintptr_t>(w.p) % 16 == 0) ? 1 : 0;
     hipLaunchKernelGGL(k_qrb_init<T>, dim3((unsigned)std::min<int64_t>(cdivb(n, 4), 8192)), dim3(256), 0, c->stream, w, jpvt, J->pos, J->vn1, J->vn2, J->flag);
     // candidate budget: about RC_QRCP_CAND_MB of column data (L2-resident across the steps of a panel), at least 4 NB columns
@@ -1455,7 +1455,7 @@ bool qrb_finish(BlockedQrcpJob<T> *J) {
     if (check) {
         ArenaMark mk(c);
         int *mark = c->alloc<int>((size_t)n + 4);
-        RC_HIP(hipMemsetAsync(mark, 0, ((size_t)n + 4) * sizeof(int), c->stream));
+        fill_words(c, mark, ((size_t)n + 4) * sizeof(int), 0u);
         hipLaunchKernelGGL(k_qrb_check_perm, dim3((unsigned)std::min<int64_t>(cdivb(n, 256), 1024)), dim3(256), 0, c->stream, J->jpvt, J->pos, (int)n, mark, mark + n);
         int bad[3] = {0, 0, 0};
         RC_HIP(hipMemcpyAsync(bad, mark + n, sizeof(bad), hipMemcpyDeviceToHost, c->stream));

@@ -569,7 +569,7 @@ static void jacobi_global(rc_context *c, Mat<T> g, Mat<T> v, Mat<T> uc, T *s, Ma
     int *state = c->alloc<int>(4);
     T *sig = c->alloc<T>((size_t)n);
     int *order = c->alloc<int>((size_t)n);
-    RC_HIP(hipMemsetAsync(state, 0, 4 * sizeof(int), c->stream));
+    fill_words(c, state, 4 * sizeof(int), 0u);
     fill_identity(c, v);
     // outside a graph capture the convergence flag is read back after every sweep; inside one a fixed number
     // of sweeps is recorded (converged sweeps return immediately)
@@ -635,8 +635,8 @@ static void launch_lds_impl(rc_context *c, Mat<T> g, Mat<T> uc, T *s, Mat<T> vc,
     else hipLaunchKernelGGL((k_jacobi_replay_v<T, 1>), grid, dim3(256), lds_v, c->stream, n, log, sweeps, order, vc);
     if (c->prof_on && !c->capturing) {  // diagnostic: number of sweeps, reported through the profile table
         int h = 0;
+        (void)hipMemcpyAsync(&h, sweeps, sizeof(int), hipMemcpyDeviceToHost, c->stream);  // on the context's own stream
         (void)hipStreamSynchronize(c->stream);
-        (void)hipMemcpy(&h, sweeps, sizeof(int), hipMemcpyDeviceToHost);
         char nm[64];
         snprintf(nm, sizeof(nm), "info:jacobi_sweeps n=%d", n);
         auto &a = c->prof_acc[nm];

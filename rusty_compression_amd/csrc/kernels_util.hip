@@ -203,11 +203,33 @@ __global__ __launch_bounds__(256) void k_invert_perm(const int64_t *perm, int64_
         if (e >= 0 && e < n) inv[e] = i;
     }
 }
+// Buffers are cleared / filled by kernels of the library on the context's stream, never by hipMemset*: a kernel node is captured into
+// a hipGraph like every other node of the path, and its value is a kernel argument ("memset nodes").
+__global__ __launch_bounds__(256) void k_fill_words(unsigned *p, size_t nwords, unsigned v) {
+    const size_t tid = blockIdx.x * (size_t)blockDim.x + threadIdx.x, nt = (size_t)gridDim.x * blockDim.x;
+    if ((reinterpret_cast<uintptr_t>(p) & 15) == 0) {
+        const size_t n4 = nwords / 4;
+        uint4 *q = reinterpret_cast<uint4 *>(p);
+        const uint4 v4 = make_uint4(v, v, v, v);
+        for (size_t i = tid; i < n4; i += nt) q[i] = v4;
+        for (size_t i = n4 * 4 + tid; i < nwords; i += nt) p[i] = v;
+    } else {
+        for (size_t i = tid; i < nwords; i += nt) p[i] = v;
+    }
+}
+void fill_words(rc_context *c, void *p, size_t bytes, unsigned v) {
+    if (bytes == 0) return;
+    RC_REQUIRE((bytes & 3) == 0 && (reinterpret_cast<uintptr_t>(p) & 3) == 0, RC_INVALID_ARGUMENT, "fill_words: %zu bytes at %p is not a whole number of aligned words", bytes, p);
+    const size_t nwords = bytes / 4;
+    const unsigned grid = (unsigned)std::min<size_t>((nwords / 4 + 255) / 256 + 1, 2048);
+    hipLaunchKernelGGL(k_fill_words, dim3(grid), dim3(256), 0, c->stream, static_cast<unsigned *>(p), nwords, v);
+}
+
 void invert_perm(rc_context *c, const int64_t *perm, int64_t n, int64_t *inv) {
     if (n <= 0) return;
     // every entry starts at -1: an input that is not a permutation leaves -1 behind, which the gathers reject (health bit 32)
     // instead of following whatever the buffer held
-    RC_HIP(hipMemsetAsync(inv, 0xff, (size_t)n * sizeof(int64_t), c->stream));
+    fill_words(c, inv, (size_t)n * sizeof(int64_t), 0xffffffffu);
     int grid = (int)std::min<int64_t>(cdiv(n, 256), 4096);
     hipLaunchKernelGGL(k_invert_perm, dim3(grid), dim3(256), 0, c->stream, perm, n, inv);
 }

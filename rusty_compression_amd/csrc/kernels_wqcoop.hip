@@ -428,7 +428,8 @@ static unsigned *coop_semaphore(int device) {
     unsigned *&s = sems[device & 63];
     if (!s) {
         RC_HIP(hipMalloc(reinterpret_cast<void **>(&s), 64));
-        RC_HIP(hipMemset(s, 0, 64));
+        const unsigned zeros[16] = {};
+        RC_HIP(hipMemcpy(s, zeros, 64, hipMemcpyHostToDevice));  // blocking copy from pageable memory: complete before any stream can see the word
     }
     return s;
 }

@@ -130,7 +130,8 @@ void rc_context::prof_resolve() {
 int *rc_context::health_word() {
     if (!health) {
         RC_HIP(hipMalloc(reinterpret_cast<void **>(&health), sizeof(int)));
-        RC_HIP(hipMemset(health, 0, sizeof(int)));
+        const int zero = 0;
+        RC_HIP(hipMemcpy(health, &zero, sizeof(int), hipMemcpyHostToDevice));  // blocking, complete before the first kernel that ORs into it
     }
     return health;
 }
@@ -267,10 +268,19 @@ __global__ void k_set_word(int *dst, int v) {
 // Runs `fast(flag)` (which ORs failure bits into the device int `flag`) and reports whether
 // its result may be kept.  Outside graph capture the flag is read back (one small sync) so
 // the caller can fall back; during capture the bits go to the context's health word instead.
+// RC_DEBUG_MEMSET_PATH (diagnostic, bit mask): 1 = the certificate word is cleared by hipMemsetAsync again (a memset NODE when the call
+// is captured), 2 = rc_get_health reads and clears through the null stream (pageable hipMemcpy + hipMemset) again -- the two round-2
+// code paths, switchable one at a time so that tools/rsvd_repeat_diag.py shows which of them delivers the byte patterns.
+static int debug_memset_path() {
+    static const int v = [] { const char *e = getenv("RC_DEBUG_MEMSET_PATH"); return e ? atoi(e) : 0; }();
+    return v;
+}
+
 template <typename F>
 bool run_certified(rc_context *c, F &&fast) {
     int *flag = c->alloc<int>(1);
-    hipLaunchKernelGGL(k_set_word, dim3(1), dim3(64), 0, c->stream, flag, 0);
+    if (debug_memset_path() & 1) RC_HIP(hipMemsetAsync(flag, 0, sizeof(int), c->stream));
+    else hipLaunchKernelGGL(k_set_word, dim3(1), dim3(64), 0, c->stream, flag, 0);
     fast(flag);
     if (c->capturing) {
         hipLaunchKernelGGL(k_or_flag, dim3(1), dim3(64), 0, c->stream, c->health_word(), flag);
@@ -766,7 +776,7 @@ void rsvd_id_row_sharded(rc_comm *comm, rc_context *c, Mat<T> a, int64_t k, int6
         const size_t blk = (size_t)l * (size_t)rr.rs;  // one rank's factor incl. the row padding of the temporaries
         Mat<T> sall = rowmajor(c->alloc<T>(blk * (size_t)world), (int64_t)world * l, l, rr.rs);
         Mat<T> sr = sall.sub((int64_t)rank * l, l, 0, l);
-        RC_HIP(hipMemsetAsync(sr.p, 0, blk * sizeof(T), c->stream));
+        fill_words(c, sr.p, blk * sizeof(T), 0u);
         gather_cols(c, rr, inv, sr);  // S_r = R_r P_r^T
         if (comm) comm_ok(rc_comm_all_gather(comm, c, sr.p, sall.p, blk * sizeof(T)), "all-gather");
         Mat<T> ws = tmp_colmajor<T>(c, sall.rows, l), qs = tmp_colmajor<T>(c, sall.rows, k);
@@ -778,7 +788,7 @@ void rsvd_id_row_sharded(rc_comm *comm, rc_context *c, Mat<T> a, int64_t k, int6
     Mat<T> b = tmp_rowmajor<T>(c, k, n);
     {
         ProfScope ps(c, "stage:sharded project B = sum_r range_r^H A_r (all-reduce)");
-        if (b.rs != n) RC_HIP(hipMemsetAsync(b.p, 0, (size_t)k * (size_t)b.rs * sizeof(T), c->stream));
+        if (b.rs != n) fill_words(c, b.p, (size_t)k * (size_t)b.rs * sizeof(T), 0u);
         project(c, range, a, b);
         if (comm) comm_ok(rc_comm_all_reduce_sum(comm, c, b.p, (size_t)k * (size_t)b.rs, (int32_t)sizeof(T)), "all-reduce");
     }
@@ -1046,6 +1056,14 @@ rc_status rc_get_health(rc_context *ctx, int32_t *word) {
     if (!ctx->health) return RC_OK;
     // read and clear on the context's own stream (pinned read-back, then a one-thread kernel): no null-stream traffic
     int h = 0;
+    if (debug_memset_path() & 2) {  // diagnostic: the round-2 path
+        hipError_t e = hipStreamSynchronize(ctx->stream);
+        if (e == hipSuccess) e = hipMemcpy(&h, ctx->health, sizeof(int), hipMemcpyDeviceToHost);
+        if (e == hipSuccess) e = hipMemset(ctx->health, 0, sizeof(int));
+        if (e != hipSuccess) { ctx->last_error = hipGetErrorString(e); return RC_RUNTIME_ERROR; }
+        *word = h;
+        return RC_OK;
+    }
     try {
         read_back(ctx, ctx->health, &h, 1);
         hipLaunchKernelGGL(k_set_word, dim3(1), dim3(64), 0, ctx->stream, ctx->health, 0);

@@ -196,6 +196,7 @@ template <typename T> void fill_zero(rc_context *c, Mat<T> dst);
 template <typename T> void scale_rows(rc_context *c, const T *s, Mat<T> src, Mat<T> dst);   // dst[i,:] = s[i] * src[i,:]
 template <typename T> void gather_cols(rc_context *c, Mat<T> src, const int64_t *idx, Mat<T> dst);  // dst[:, j] = src[:, idx[j]]
 void invert_perm(rc_context *c, const int64_t *perm, int64_t n, int64_t *inv);
+void fill_words(rc_context *c, void *p, size_t bytes, unsigned v);  // every 32-bit word of [p, p + bytes) = v, by a kernel on c->stream (no hipMemset*)
 void iota_i64(rc_context *c, int64_t *p, int64_t n);
 // column 2-norms squared; out[j] = sum_i a(i,j)^2
 template <typename T> void col_sumsq(rc_context *c, Mat<T> a, T *out);

@@ -219,8 +219,8 @@ void c_gemm(rc_context *c, int opa, int opb, cplx<R> alpha, CV<R> a, CV<R> b, cp
     R *br = c->alloc<R>((size_t)ldb * n), *bi = c->alloc<R>((size_t)ldb * n);
     R *cr = c->alloc<R>((size_t)ldc * n), *ci = c->alloc<R>((size_t)ldc * n);
     if (k == 0) {  // empty inner dimension: C = beta C
-        RC_HIP(hipMemsetAsync(cr, 0, (size_t)ldc * n * sizeof(R), c->stream));
-        RC_HIP(hipMemsetAsync(ci, 0, (size_t)ldc * n * sizeof(R), c->stream));
+        fill_words(c, cr, (size_t)ldc * n * sizeof(R), 0u);
+        fill_words(c, ci, (size_t)ldc * n * sizeof(R), 0u);
         hipLaunchKernelGGL(k_c_combine<R>, dim3((unsigned)std::min<int64_t>(cdivi(m * n, 256), 8192)), dim3(256), 0, c->stream, cr, ci, ldc, alpha, beta, cm);
         return;
     }
@@ -548,7 +548,7 @@ void c_jacobi_svd_tall(rc_context *c, CV<R> g, CV<R> uc, R *s, CV<R> vc) {
     R *sig = c->alloc<R>((size_t)n);
     int *order = c->alloc<int>((size_t)n);
     CV<R> v = tmp_cm<R>(c, n, n);
-    RC_HIP(hipMemsetAsync(state, 0, 4 * sizeof(int), c->stream));
+    fill_words(c, state, 4 * sizeof(int), 0u);
     c_fill(c, v, true);
     RC_REQUIRE(!c->capturing, RC_RUNTIME_ERROR, "complex SVD reads its convergence flag back: not capturable");
     const unsigned grid = (unsigned)((N / 2 + 3) / 4);
