@@ -264,6 +264,18 @@ struct DirectRows {
             }
         }
     }
+    // iteration I of copy() alone (one unit = one piece, plus its masked tail piece): k_gemm_f64r spreads a tile's copies over its MFMA stream
+    static constexpr int UNITS = PER_WAVE;
+    template <int I>
+    __device__ inline void copy_unit(__amdgpu_buffer_rsrc_t rsrc, uint32_t tile_off, double *stage, int wave_u, int lane) const {
+        const int kk = wave_u * (PER_WAVE / PIECES_ROW) + I / PIECES_ROW;
+        constexpr int h = I % PIECES_ROW;
+        const uint32_t soff = __builtin_amdgcn_readfirstlane(tile_off + kk * sk8);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_ptr_t)(stage + kk * P + h * 128), 16, voff[h], soff, 0, 0);
+        if constexpr (MASKTAIL) {
+            if (lane < TAIL / 2) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_ptr_t)(stage + kk * P + 128), 16, voff[1], soff, 0, 0);
+        }
+    }
     // fragment address (doubles) of row r, reduction index k
     static __device__ inline int at(int r, int k) { return k * P + r; }
 };
@@ -294,6 +306,13 @@ struct DirectK {
             const uint32_t soff = __builtin_amdgcn_readfirstlane(tile_off + piece * sr64);
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_ptr_t)(stage + piece * 8 * BK), 16, voff[i & 1], soff, 0, 0);
         }
+    }
+    static constexpr int UNITS = PER_WAVE;
+    template <int I>
+    __device__ inline void copy_unit(__amdgpu_buffer_rsrc_t rsrc, uint32_t tile_off, double *stage, int wave_u, int /*lane*/) const {
+        const int piece = wave_u * PER_WAVE + I;
+        const uint32_t soff = __builtin_amdgcn_readfirstlane(tile_off + piece * sr64);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_ptr_t)(stage + piece * 8 * BK), 16, voff[I & 1], soff, 0, 0);
     }
 };
 
@@ -586,6 +605,193 @@ __global__ __launch_bounds__(WM *WN * 64, 2) void k_gemm_f64a(GemmArgs<double> g
         }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// k_gemm_f64r: k_gemm_f64a's hand-ordered loop on a THREE-stage LDS ring (round 3).  What k_gemm_f64a still lost were the phases
+// that are synchronous across the workgroup (ablation, DESIGN.md section 3: copy issue 8 %, barrier 4.5 % of the loop): at the
+// end of sub-step 2 every wave drained its LDS reads (lgkmcnt(0): the stage it had just read was about to be overwritten), met
+// the others, and then all eight waves issued their copies of the next tile at once -- no wave issues an MFMA meanwhile.  Here
+//   * the copies of tile t + 2 go into the stage of tile t - 1, whose last reads every wave completed before it reached the
+//     barrier of tile t: the barrier needs no drain of LDS reads any more -- fragment prefetches stay in flight across it --
+//     and waits (vmcnt(0)) only for copies that were issued more than two sub-steps earlier;
+//   * a wave's copies are single instructions INSIDE its MFMA stream (one behind each of the first MFMA groups of a sub-step),
+//     the older half of the workgroup in sub-step 3 and the younger half (waves NW/2 ..: the SIMD partners of the first half)
+//     in sub-step 0 of the next tile, so the issue of one wave's copy is covered by its partner's MFMAs on the same SIMD.
+// Tiles, wave tiles, LDS images, fragment rotation and counted waits are k_gemm_f64a's; one stage more of LDS (154 / 160 KB).
+// ---------------------------------------------------------------------------------------------------------------------
+template <int TM, int TN, int OFF0, int ISTRIDE, class F, int... I>
+__device__ inline void asm_groups_c(double (&acc)[TM][TN], double (&fa)[TM], const double (&fb)[TN], uint32_t va, F &&after, std::integer_sequence<int, I...>) {
+    ((asm_group<TM, TN, OFF0, ISTRIDE, I>(acc, fa, fb, va), after(std::integral_constant<int, I>{})), ...);
+}
+
+template <int BLAY, int ORIENT, int BM, int BN, int WM, int WN, bool MASKTAIL>
+__global__ __launch_bounds__(WM *WN * 64, 2) void k_gemm_f64r(GemmArgs<double> g) {
+    constexpr int BK = 16, NSTAGE = 3;
+    constexpr int NT = WM * WN * 64, NW = WM * WN;
+    constexpr int WR = BM / WM, WC = BN / WN;
+    constexpr int AM = ORIENT == 0 ? 4 : 16, BNW = ORIENT == 0 ? 16 : 4;
+    constexpr int TM = WR / AM, TN = WC / BNW;
+    static_assert((BLAY == 1 && ORIENT == 0) || (BLAY == 0 && ORIENT == 1), "instantiated pairings");
+    static_assert(WR % AM == 0 && WC % BNW == 0 && TM + TN - 1 >= 15, "wave tile shape (and at least 15 reads between a fragment's read and its use)");
+    typedef DirectRows<BM, BK, NT, MASKTAIL> SA;
+    typedef DirectRows<BN, BK, NT> SBR;
+    typedef DirectK<BN, BK, NT> SBK;
+    constexpr int PA = SA::P, PB = SBR::P;
+    constexpr int A_ELEMS = SA::ELEMS, STAGE = SA::ELEMS + (BLAY == 0 ? SBR::ELEMS : SBK::ELEMS);
+    constexpr int UA = SA::UNITS, UB = BLAY == 0 ? SBR::UNITS : SBK::UNITS, NUNITS = UA + UB;
+    static_assert(NUNITS <= TM - 1, "one copy behind each of the MFMA groups 1 .. NUNITS of a sub-step");
+
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    double *smem = reinterpret_cast<double *>(smem_raw);
+    const uint32_t lds0 = (uint32_t)reinterpret_cast<uintptr_t>((__attribute__((address_space(3))) char *)smem_raw);
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    const bool early = wave_u < NW / 2;
+    const int wm = wave / WN, wn = wave % WN;
+    const int lk = lane >> 4;
+    const int la = ORIENT == 0 ? (lane & 3) : (lane & 15);
+    const int lbn = ORIENT == 0 ? (lane & 15) : (lane & 3);
+
+    const int ntiles = g.tiles_m * g.tiles_n;
+    int bid = blockIdx.x;
+    {
+        const int q = ntiles / 8, r = ntiles % 8, xcd = bid % 8, idx = bid / 8;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    const int tile_n = bid % g.tiles_n, tile_m = bid / g.tiles_n;
+    const int64_t m0 = (int64_t)tile_m * BM, n0 = (int64_t)tile_n * BN;
+    const int split = blockIdx.y;
+    const int64_t kbeg = (int64_t)split * g.kchunk;
+    const int64_t kend = min(g.K, kbeg + g.kchunk);
+    const int nk = (int)((kend - kbeg) / BK);
+
+    double acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = 0.0;
+
+    SA sa;
+    SBR sbr;
+    SBK sbk;
+    sa.init(g.M - m0, g.sak, lane);
+    if (BLAY == 0) sbr.init(g.N - n0, g.sbk, lane);
+    else sbk.init(g.sbn, lane);
+    const __amdgpu_buffer_rsrc_t a_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<double *>(g.a + m0 * g.sam + kbeg * g.sak), 0, 0x7fffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t b_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<double *>(g.b + n0 * g.sbn + kbeg * g.sbk), 0, 0x7fffffff, 0x00020000);
+    const uint32_t a_step = (uint32_t)(BK * g.sak * 8), b_step = (uint32_t)(BK * g.sbk * 8);
+    // copy unit U of tile t into `stage` (U < UA: the A operand's pieces of this wave, then the B operand's)
+    auto copy_unit = [&](auto uc, int t, double *stage) {
+        constexpr int U = decltype(uc)::value;
+        if constexpr (U < UA) sa.template copy_unit<U>(a_rsrc, t * a_step, stage, wave_u, lane);
+        else if constexpr (BLAY == 0) sbr.template copy_unit<U - UA>(b_rsrc, t * b_step, stage + A_ELEMS, wave_u, lane);
+        else sbk.template copy_unit<U - UA>(b_rsrc, t * b_step, stage + A_ELEMS, wave_u, lane);
+    };
+    auto copy_tile = [&](int t, double *stage) {
+        sa.copy(a_rsrc, t * a_step, stage, wave_u, lane);
+        if (BLAY == 0) sbr.copy(b_rsrc, t * b_step, stage + A_ELEMS, wave_u, lane);
+        else sbk.copy(b_rsrc, t * b_step, stage + A_ELEMS, wave_u);
+    };
+
+    const uint32_t a_addr = lds0 + (uint32_t)(lk * PA + wm * WR + la) * 8;
+    const uint32_t b_addr = BLAY == 1 ? lds0 + (uint32_t)(A_ELEMS + (wn * WC + lbn) * BK + (lk & 1)) * 8
+                                      : lds0 + (uint32_t)(A_ELEMS + lk * PB + wn * WC + lbn) * 8;
+    const uint32_t swz8 = BLAY == 1 ? (uint32_t)((((lk >> 1) ^ (lbn >> 1)) & 7) * 16) : 0u;
+    constexpr int ISTRIDE = AM * 8, AKS = 4 * PA * 8;
+    constexpr int JSTRIDE = BLAY == 1 ? 16 * BK * 8 : BNW * 8, BKS = BLAY == 1 ? 0 : 4 * PB * 8;
+    auto b_base = [&](uint32_t stage_off, int ks) -> uint32_t { return BLAY == 1 ? b_addr + stage_off + (swz8 ^ (uint32_t)(ks * 32)) : b_addr + stage_off; };
+    auto nothing = [](auto) {};
+
+    // prologue: tile 0 by everyone; tile 1 by the older half now, by the younger half inside sub-step 0 of tile 0 (its regular slot)
+    copy_tile(0, smem);
+    if (early && nk > 1) copy_tile(1, smem + STAGE);
+    asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+
+    double fa[TM], fb[2][TN];
+    asm_read_b<TN, 0, JSTRIDE>(fb[0], b_base(0, 0), std::make_integer_sequence<int, TN>{});
+    asm_read_a<TM, 0, ISTRIDE>(fa, a_addr, std::make_integer_sequence<int, TM>{});
+
+    int s_cur = 0;  // stage of tile `it`
+    for (int it = 0; it < nk; ++it) {
+        const int s_nxt = s_cur == NSTAGE - 1 ? 0 : s_cur + 1, s_prv = s_cur == 0 ? NSTAGE - 1 : s_cur - 1;
+        const uint32_t cur_off = (uint32_t)(s_cur * STAGE * 8), nxt_off = (uint32_t)(s_nxt * STAGE * 8);
+        {   // sub-step 0; younger half: its copies of tile it + 1 (stage free since the barrier of tile it - 1)
+            const bool go = !early && it + 1 < nk;
+            double *dst = smem + s_nxt * STAGE;
+            asm_read_b<TN, 1 * BKS, JSTRIDE>(fb[1], b_base(cur_off, 1), std::make_integer_sequence<int, TN>{});
+            asm_groups_c<TM, TN, 1 * AKS, ISTRIDE>(acc, fa, fb[0], a_addr + cur_off, [&](auto ic) {
+                constexpr int I = decltype(ic)::value;
+                if constexpr (I >= 1 && I - 1 < NUNITS) { if (go) copy_unit(std::integral_constant<int, I - 1>{}, it + 1, dst); }
+            }, std::make_integer_sequence<int, TM>{});
+        }
+        {
+            asm_read_b<TN, 2 * BKS, JSTRIDE>(fb[0], b_base(cur_off, 2), std::make_integer_sequence<int, TN>{});
+            asm_groups_c<TM, TN, 2 * AKS, ISTRIDE>(acc, fa, fb[1], a_addr + cur_off, nothing, std::make_integer_sequence<int, TM>{});
+        }
+        {
+            asm_read_b<TN, 3 * BKS, JSTRIDE>(fb[1], b_base(cur_off, 3), std::make_integer_sequence<int, TN>{});
+            asm_groups_c<TM, TN, 3 * AKS, ISTRIDE>(acc, fa, fb[0], a_addr + cur_off, nothing, std::make_integer_sequence<int, TM>{});
+            // tile it + 1 has landed in its stage (this wave's copies: vmcnt(0); everyone's: the barrier); every wave that passes has
+            // finished reading tile it - 1.  The fragment reads for sub-step 3 stay in flight.
+            asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+        }
+        {   // sub-step 3; older half: its copies of tile it + 2 into the stage of tile it - 1
+            const bool go = early && it + 2 < nk;
+            double *dst = smem + s_prv * STAGE;
+            asm_read_b<TN, 0, JSTRIDE>(fb[0], b_base(nxt_off, 0), std::make_integer_sequence<int, TN>{});
+            asm_groups_c<TM, TN, 0, ISTRIDE>(acc, fa, fb[1], a_addr + nxt_off, [&](auto ic) {
+                constexpr int I = decltype(ic)::value;
+                if constexpr (I >= 1 && I - 1 < NUNITS) { if (go) copy_unit(std::integral_constant<int, I - 1>{}, it + 2, dst); }
+            }, std::make_integer_sequence<int, TM>{});
+        }
+        s_cur = s_nxt;
+    }
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");  // prefetched fragments of the (non-existent) next tile
+
+    const int er = ORIENT == 0 ? (lane >> 4) : (((lane >> 2) & 3) * 4 + (lane >> 4));
+    const int ec = ORIENT == 0 ? (lane & 15) : (lane & 3);
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int64_t gm = m0 + wm * WR + i * AM + er;
+            const int64_t gn = n0 + wn * WC + j * BNW + ec;
+            if (gm < g.M && gn < g.N) {
+                const double v = acc[i][j];
+                if (g.splits > 1) {
+                    g.partial[((int64_t)split * g.M + gm) * g.N + gn] = v;
+                } else {
+                    double *cp = g.c + gm * g.scm + gn * g.scn;
+                    *cp = g.beta == 0.0 ? g.alpha * v : g.alpha * v + g.beta * (*cp);
+                }
+            }
+        }
+}
+
+template <int BLAY, int ORIENT, int BM, int BN, int WM, int WN, bool MASKTAIL>
+static bool launch_r(rc_context *c, const GemmArgs<double> &g) {
+    constexpr int NT = WM * WN * 64;
+    constexpr size_t lds = 3 * (size_t)(DirectRows<BM, 16, NT, MASKTAIL>::ELEMS + (BLAY == 0 ? DirectRows<BN, 16, NT>::ELEMS : DirectK<BN, 16, NT>::ELEMS)) * sizeof(double);
+    static_assert(lds <= 160 * 1024, "ring does not fit LDS");
+    if (g.sam != 1) return false;
+    if (BLAY == 0 ? g.sbn != 1 : (g.sbk != 1 || g.N % BN != 0)) return false;
+    const int64_t a_span = ((int64_t)256 * g.sam + g.kchunk * g.sak + 2) * 8;
+    const int64_t b_span = ((int64_t)BN * g.sbn + g.kchunk * g.sbk + 2) * 8;
+    if (a_span >= (1ll << 31) || b_span >= (1ll << 31) || g.sak < 0 || g.sbn < 0 || g.sbk < 0) return false;
+    auto kern = k_gemm_f64r<BLAY, ORIENT, BM, BN, WM, WN, MASKTAIL>;
+    static bool attr_set[64] = {};
+    if (!attr_set[c->device & 63]) {
+        RC_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_set[c->device & 63] = true;
+    }
+    char nm[128];
+    snprintf(nm, sizeof(nm), "k_gemm_f64r<%d,%d,%d,%d,%d,%d,%s>", BLAY, ORIENT, BM, BN, WM, WN, MASKTAIL ? "true" : "false");
+    c->last_gemm_kernel = nm;
+    ProfScope ps(c, "kernel:k_gemm_mfma<f64> M=%lld N=%lld K=%lld", (long long)g.M, (long long)g.N, (long long)g.K);
+    hipLaunchKernelGGL(kern, dim3((unsigned)(g.tiles_m * g.tiles_n), (unsigned)g.splits), dim3(NT), lds, c->stream, g);
+    return true;
+}
+
 template <int BLAY, int ORIENT, int BM, int BN, int WM, int WN, bool MASKTAIL>
 static bool launch_a(rc_context *c, const GemmArgs<double> &g) {
     constexpr int NT = WM * WN * 64;
@@ -685,6 +891,10 @@ bool gemm_f64p_launch(rc_context *c, const GemmArgs<double> &g, int alay, int bl
     if (direct && alay == 1 && bk == 16) {
         // hand-ordered main loop (k_gemm_f64a) on two 4-wave workgroups per CU, where kernels_gemm.hip chose 128-column tiles for it
         static const int wide_asm = [] { const char *e = getenv("RC_GEMM_PIPE_ASM"); return e ? atoi(e) : 1; }();  // 0: the compiler-scheduled loops (k_gemm_f64d / k_gemm_f64p)
+        // three-stage ring with the copies inside the MFMA stream (k_gemm_f64r); RC_GEMM_RING=0: the two-stage k_gemm_f64a
+        static const int ring = [] { const char *e = getenv("RC_GEMM_RING"); return e ? atoi(e) : 1; }();
+        if (wide_asm && ring && blay == 1 && bm == 136 && bn == 256 && wm == 2 && wn == 4 && orient == 0 && launch_r<1, 0, 136, 256, 2, 4, true>(c, g)) return true;
+        if (wide_asm && ring && blay == 0 && bm == 128 && bn == 256 && wm == 1 && wn == 8 && orient == 1 && launch_r<0, 1, 128, 256, 1, 8, false>(c, g)) return true;
         if (wide_asm && blay == 1 && bm == 136 && bn == 256 && wm == 2 && wn == 4 && orient == 0 && launch_a<1, 0, 136, 256, 2, 4, true>(c, g)) return true;
         if (wide_asm && blay == 0 && bm == 128 && bn == 256 && wm == 1 && wn == 8 && orient == 1 && launch_a<0, 1, 128, 256, 1, 8, false>(c, g)) return true;
         if (blay == 1 && bm == 136 && bn == 128 && wm == 2 && wn == 2 && orient == 0 && launch_a<1, 0, 136, 128, 2, 2, true>(c, g)) return true;
@@ -708,4 +918,6 @@ template __global__ void k_gemm_f64a<1, 0, 136, 256, 2, 4, true>(GemmArgs<double
 template __global__ void k_gemm_f64a<0, 1, 128, 256, 1, 8, false>(GemmArgs<double>);
 template __global__ void k_gemm_f64a<0, 1, 128, 128, 1, 4, false>(GemmArgs<double>);
 template __global__ void k_gemm_f64d<0, 128, 256, 16, 1, 8, 1>(GemmArgs<double>);
+template __global__ void k_gemm_f64r<1, 0, 136, 256, 2, 4, true>(GemmArgs<double>);
+template __global__ void k_gemm_f64r<0, 1, 128, 256, 1, 8, false>(GemmArgs<double>);
 }

@@ -59,9 +59,11 @@ def test_gemm_all_layouts_and_ragged_shapes(dtype, tol):
     assert rel(npy(rc.conj_matmat(big, y)), big.T.astype(np.float64) @ y) <= tol
 
 
-@pytest.mark.parametrize("opt", ["default", "two_workgroups"])
+@pytest.mark.parametrize("opt", ["default", "two_workgroups", "two_stage"])
 def test_f64_gemm_hand_ordered_loops_on_their_shapes(opt):
-    """k_gemm_f64a (hand-ordered main loop, direct-to-LDS copies, masked tail copy): the shapes that reach its instantiations --
+    """k_gemm_f64r (round 3, the default: three-stage LDS ring, copies inside the MFMA stream) and k_gemm_f64a (two stages;
+    `two_stage` = RC_GEMM_RING=0, `two_workgroups` = its 2 x 4-wave variant) -- hand-ordered main loops, direct-to-LDS copies,
+    masked tail copy: the shapes that reach their instantiations --
     129..136 rows over a K-contiguous wide operand (the sketch as the transposed problem) and <= 128 rows over an N-contiguous
     one (the projection) -- around their preconditions: row counts that clamp, one K tile, K tiles that split, wide / narrow N,
     plus neighbours that must fall back to the compiler-scheduled kernels (K not a multiple of 16, N not a multiple of the tile)."""
@@ -69,10 +71,11 @@ def test_f64_gemm_hand_ordered_loops_on_their_shapes(opt):
     import subprocess
     import sys
 
-    if opt == "two_workgroups" and os.environ.get("RC_GEMM_SKETCH_2WG") != "1":
-        # the knob is read once per process: run this parametrization in a child with it set
-        env = dict(os.environ, RC_GEMM_SKETCH_2WG="1")
-        res = subprocess.run([sys.executable, "-m", "pytest", __file__, "-m", "gpu", "-q", "-x", "-k", "hand_ordered_loops and two_workgroups"], env=env, capture_output=True, text=True, timeout=600)
+    knob = {"two_workgroups": ("RC_GEMM_SKETCH_2WG", "1"), "two_stage": ("RC_GEMM_RING", "0")}.get(opt)
+    if knob and os.environ.get(knob[0]) != knob[1]:
+        # the knobs are read once per process: run this parametrization in a child with it set
+        env = dict(os.environ, **{knob[0]: knob[1]})
+        res = subprocess.run([sys.executable, "-m", "pytest", __file__, "-m", "gpu", "-q", "-x", "-k", "hand_ordered_loops and " + opt], env=env, capture_output=True, text=True, timeout=600)
         assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-1000:]
         return
     rng = np.random.default_rng(5)
