@@ -311,6 +311,56 @@ rc_status rc_sample_range_power_iteration_f32(rc_context *ctx, rc_matrix a, int6
 rc_status rc_sample_range_adaptive_f64(rc_context *ctx, rc_matrix a, double rel_tol, int64_t sample_size, rc_matrix omegas, uint64_t seed, rc_matrix q_cap, int64_t *rank, int64_t *hist_rank, double *hist_res, int64_t hist_cap, int64_t *hist_len);
 rc_status rc_sample_range_adaptive_f32(rc_context *ctx, rc_matrix a, double rel_tol, int64_t sample_size, rc_matrix omegas, uint64_t seed, rc_matrix q_cap, int64_t *rank, int64_t *hist_rank, double *hist_res, int64_t hist_cap, int64_t *hist_len);
 
+/* ------------------------------------------------ operators behind callbacks -- */
+/* The reference's range finders are implemented for ANY operator, not only for dense arrays:
+ *   impl<Op: MatMat> SampleRange for Op            src/random_sampling.rs:102
+ *   impl<Op: MatMat + ConjMatMat> SampleRangePowerIteration for Op   :130
+ *   impl<Op: MatMat + ConjMatMat> AdaptiveSampling for Op            :222
+ *   QRTraits / SVDTraits::compute_from_range_estimate<Op: ConjMatMat>   src/qr.rs:311-323, src/svd.rs:171-183
+ * (trait contract: src/types.rs:40-51 nrows / ncols / matvec, :77-81 conj_matvec, :58-71 / :88-101 the derived products).
+ * rc_operator is that contract at the C ABI: the extents and the two PRODUCTS (the per-column matvec loop of the blanket impl
+ * src/types.rs:145-146 is the host's business -- a host with only a matvec loops over the columns of x inside its callback).
+ *   matmat(user, ctx, x, y):       y (rows x s) = A x,    x: cols x s
+ *   conj_matmat(user, ctx, x, y):  y (cols x s) = A^H x,  x: rows x s      (may be NULL where only MatMat is required)
+ * x and y are strided DEVICE views (any layout; y may be the transposed view of a row-major buffer) owned by the library for the
+ * duration of the call.  A callback enqueues its work on the context's stream (rc_get_stream) -- it may call this library's own
+ * entry points with the SAME ctx (they nest: the outer call's workspace stays intact) or launch kernels of its own -- and returns
+ * RC_OK or a status that the calling entry point then returns (rc_last_error_message names the product).  It must not synchronise
+ * unless it has to; it cannot be recorded into a hipGraph (RC_INVALID_ARGUMENT while capturing).
+ * The *_op_* entry points below run the same internal steps as their dense twins with the two products replaced by the callbacks:
+ * a dense matrix behind callbacks that call rc_matmat / rc_conj_matmat reproduces the dense entry point bit for bit (f64; the f32
+ * products pick their tiles by operand layout, so there the agreement is to rounding). */
+typedef struct rc_operator rc_operator;
+typedef int32_t (*rc_operator_product_fn)(void *user, rc_context *ctx, rc_matrix x, rc_matrix y); /* returns an rc_status */
+struct rc_operator {
+    int64_t rows;                       /* MatVec::nrows  src/types.rs:44-45 */
+    int64_t cols;                       /* MatVec::ncols  src/types.rs:47-48 */
+    rc_operator_product_fn matmat;      /* MatMat::matmat          src/types.rs:58-71  */
+    rc_operator_product_fn conj_matmat; /* ConjMatMat::conj_matmat src/types.rs:88-101 */
+    void *user;
+};
+/* the hipStream_t the context orders its work on (for a callback's own kernels) */
+rc_status rc_get_stream(rc_context *ctx, void **hip_stream);
+/* SampleRange for Op (src/random_sampling.rs:102-121) */
+rc_status rc_sample_range_by_rank_op_f64(rc_context *ctx, const rc_operator *op, int64_t k, int64_t p, rc_matrix omega, uint64_t seed, rc_matrix q);
+rc_status rc_sample_range_by_rank_op_f32(rc_context *ctx, const rc_operator *op, int64_t k, int64_t p, rc_matrix omega, uint64_t seed, rc_matrix q);
+/* SampleRangePowerIteration for Op (src/random_sampling.rs:130-163) */
+rc_status rc_sample_range_power_iteration_op_f64(rc_context *ctx, const rc_operator *op, int64_t k, int64_t p, int64_t it_count, rc_matrix omega, uint64_t seed, rc_matrix q);
+rc_status rc_sample_range_power_iteration_op_f32(rc_context *ctx, const rc_operator *op, int64_t k, int64_t p, int64_t it_count, rc_matrix omega, uint64_t seed, rc_matrix q);
+/* AdaptiveSampling for Op (src/random_sampling.rs:222-277) */
+rc_status rc_sample_range_adaptive_op_f64(rc_context *ctx, const rc_operator *op, double rel_tol, int64_t sample_size, rc_matrix omegas, uint64_t seed, rc_matrix q_cap, int64_t *rank, int64_t *hist_rank, double *hist_res, int64_t hist_cap, int64_t *hist_len);
+rc_status rc_sample_range_adaptive_op_f32(rc_context *ctx, const rc_operator *op, double rel_tol, int64_t sample_size, rc_matrix omegas, uint64_t seed, rc_matrix q_cap, int64_t *rank, int64_t *hist_rank, double *hist_res, int64_t hist_cap, int64_t *hist_len);
+/* QRTraits::compute_from_range_estimate<Op: ConjMatMat> (src/qr.rs:311-323) */
+rc_status rc_qr_from_range_estimate_op_f64(rc_context *ctx, rc_matrix range, const rc_operator *op, rc_matrix q, rc_matrix r, int64_t *ind);
+rc_status rc_qr_from_range_estimate_op_f32(rc_context *ctx, rc_matrix range, const rc_operator *op, rc_matrix q, rc_matrix r, int64_t *ind);
+/* SVDTraits::compute_from_range_estimate<Op: ConjMatMat> (src/svd.rs:171-183) */
+rc_status rc_svd_from_range_estimate_op_f64(rc_context *ctx, rc_matrix range, const rc_operator *op, rc_matrix u, double *s, rc_matrix vt);
+rc_status rc_svd_from_range_estimate_op_f32(rc_context *ctx, rc_matrix range, const rc_operator *op, rc_matrix u, float *s, rc_matrix vt);
+/* the fused pipeline below (rc_rsvd_id_*) over an operator; not capturable */
+struct rc_rsvd_id_out;
+rc_status rc_rsvd_id_op_f64(rc_context *ctx, const rc_operator *op, int64_t k, int64_t p, rc_matrix omega, uint64_t seed, const struct rc_rsvd_id_out *out);
+rc_status rc_rsvd_id_op_f32(rc_context *ctx, const rc_operator *op, int64_t k, int64_t p, rc_matrix omega, uint64_t seed, const struct rc_rsvd_id_out *out);
+
 /* ------------------------------------------------ fused pipeline (bench) -- */
 /* cfg3 "rSVD + ID" in one call, no host synchronisation inside (capturable in
  * a hipGraph): sample_range_by_rank -> SVD::compute_from_range_estimate ->

@@ -9,6 +9,7 @@ column, row and two-sided interpolative decompositions.
 from ._lib import (CompressionError, Context, HipRuntimeError, LayoutError, LinalgError, PivotedQRError,  # noqa: F401
                    RustyCompressionError, default_context)
 from .col_interp_decomp import ColumnID  # noqa: F401
+from .operator import DenseOperator, LowRankOperator, Operator  # noqa: F401
 from .permutation import (MatrixPermutationMode, VectorPermutationMode, apply_permutation,  # noqa: F401
                           invert_permutation_vector)
 from .qr import LQ, QR, pivoted_lq, pivoted_qr  # noqa: F401
@@ -28,5 +29,5 @@ __all__ = [
     "sample_range_by_rank", "sample_range_power_iteration", "sample_range_adaptive", "max_col_norm",
     "matmat", "conj_matmat", "dot", "rel_diff_fro", "rel_diff_l2", "pivoted_qr", "pivoted_lq", "compute_svd",
     "RustyCompressionError", "LinalgError", "CompressionError", "LayoutError", "PivotedQRError", "HipRuntimeError",
-    "Context", "default_context",
+    "Context", "default_context", "Operator", "DenseOperator", "LowRankOperator",
 ]

@@ -266,10 +266,11 @@ struct DirectRows {
     }
     // iteration I of copy() alone (one unit = one piece, plus its masked tail piece): k_gemm_f64r spreads a tile's copies over its MFMA stream
     static constexpr int UNITS = PER_WAVE;
-    template <int I>
-    __device__ inline void copy_unit(__amdgpu_buffer_rsrc_t rsrc, uint32_t tile_off, double *stage, int wave_u, int lane) const {
+    // (I is a literal at every call site; a plain argument instead of a template parameter: clang 19 rejected the member template's
+    // substitution in the second and later instantiations of the calling kernel template)
+    __device__ __attribute__((always_inline)) void copy_unit(const int I, __amdgpu_buffer_rsrc_t rsrc, uint32_t tile_off, double *stage, int wave_u, int lane) const {
         const int kk = wave_u * (PER_WAVE / PIECES_ROW) + I / PIECES_ROW;
-        constexpr int h = I % PIECES_ROW;
+        const int h = I % PIECES_ROW;
         const uint32_t soff = __builtin_amdgcn_readfirstlane(tile_off + kk * sk8);
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_ptr_t)(stage + kk * P + h * 128), 16, voff[h], soff, 0, 0);
         if constexpr (MASKTAIL) {
@@ -308,8 +309,7 @@ struct DirectK {
         }
     }
     static constexpr int UNITS = PER_WAVE;
-    template <int I>
-    __device__ inline void copy_unit(__amdgpu_buffer_rsrc_t rsrc, uint32_t tile_off, double *stage, int wave_u, int /*lane*/) const {
+    __device__ __attribute__((always_inline)) void copy_unit(const int I, __amdgpu_buffer_rsrc_t rsrc, uint32_t tile_off, double *stage, int wave_u, int /*lane*/) const {
         const int piece = wave_u * PER_WAVE + I;
         const uint32_t soff = __builtin_amdgcn_readfirstlane(tile_off + piece * sr64);
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_ptr_t)(stage + piece * 8 * BK), 16, voff[I & 1], soff, 0, 0);
@@ -618,12 +618,20 @@ __global__ __launch_bounds__(WM *WN * 64, 2) void k_gemm_f64a(GemmArgs<double> g
 //     in sub-step 0 of the next tile, so the issue of one wave's copy is covered by its partner's MFMAs on the same SIMD.
 // Tiles, wave tiles, LDS images, fragment rotation and counted waits are k_gemm_f64a's; one stage more of LDS (154 / 160 KB).
 // ---------------------------------------------------------------------------------------------------------------------
-template <int TM, int TN, int OFF0, int ISTRIDE, class F, int... I>
+// DBG (diagnostic instantiations only, -DRC_GEMM_PIPE_DEBUG + RC_GEMM_RING_DBG): 1 = no copies in the loop, 2 = no tile barrier,
+// 4 = no fragment reads / counted waits (the MFMAs run on stale registers), 8 = no MFMAs.  Results are garbage; only the time counts.
+template <int DBG, int TM, int TN, int OFF0, int ISTRIDE, int I>
+__device__ inline void asm_group_d(double (&acc)[TM][TN], double (&fa)[TM], const double (&fb)[TN], uint32_t va) {
+    if constexpr (!(DBG & 4)) asm volatile("s_waitcnt lgkmcnt(15)" ::: "memory");
+    if constexpr (!(DBG & 8)) asm_mfma_row<TN>(acc[I], fa[I], fb, std::make_integer_sequence<int, TN>{});
+    if constexpr (!(DBG & 4)) asm_lds_read<OFF0 + I * ISTRIDE>(fa[I], va);
+}
+template <int DBG, int TM, int TN, int OFF0, int ISTRIDE, class F, int... I>
 __device__ inline void asm_groups_c(double (&acc)[TM][TN], double (&fa)[TM], const double (&fb)[TN], uint32_t va, F &&after, std::integer_sequence<int, I...>) {
-    ((asm_group<TM, TN, OFF0, ISTRIDE, I>(acc, fa, fb, va), after(std::integral_constant<int, I>{})), ...);
+    ((asm_group_d<DBG, TM, TN, OFF0, ISTRIDE, I>(acc, fa, fb, va), after(std::integral_constant<int, I>{})), ...);
 }
 
-template <int BLAY, int ORIENT, int BM, int BN, int WM, int WN, bool MASKTAIL>
+template <int BLAY, int ORIENT, int BM, int BN, int WM, int WN, bool MASKTAIL, int DBG = 0>
 __global__ __launch_bounds__(WM *WN * 64, 2) void k_gemm_f64r(GemmArgs<double> g) {
     constexpr int BK = 16, NSTAGE = 3;
     constexpr int NT = WM * WN * 64, NW = WM * WN;
@@ -680,12 +688,13 @@ __global__ __launch_bounds__(WM *WN * 64, 2) void k_gemm_f64r(GemmArgs<double> g
     const __amdgpu_buffer_rsrc_t a_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<double *>(g.a + m0 * g.sam + kbeg * g.sak), 0, 0x7fffffff, 0x00020000);
     const __amdgpu_buffer_rsrc_t b_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<double *>(g.b + n0 * g.sbn + kbeg * g.sbk), 0, 0x7fffffff, 0x00020000);
     const uint32_t a_step = (uint32_t)(BK * g.sak * 8), b_step = (uint32_t)(BK * g.sbk * 8);
-    // copy unit U of tile t into `stage` (U < UA: the A operand's pieces of this wave, then the B operand's)
-    auto copy_unit = [&](auto uc, int t, double *stage) {
-        constexpr int U = decltype(uc)::value;
-        if constexpr (U < UA) sa.template copy_unit<U>(a_rsrc, t * a_step, stage, wave_u, lane);
-        else if constexpr (BLAY == 0) sbr.template copy_unit<U - UA>(b_rsrc, t * b_step, stage + A_ELEMS, wave_u, lane);
-        else sbk.template copy_unit<U - UA>(b_rsrc, t * b_step, stage + A_ELEMS, wave_u, lane);
+    // copy unit u of tile t into `stage` (u < UA: the A operand's pieces of this wave, then the B operand's)
+    // (u is a literal at every call site and everything below is inlined; no nested generic lambdas -- clang 19's host pass fails to
+    // substitute them inside the second and later instantiations of a kernel template)
+    auto copy_unit = [&](const int u, int t, double *stage) -> void {
+        if (u < UA) sa.copy_unit(u, a_rsrc, t * a_step, stage, wave_u, lane);
+        else if (BLAY == 0) sbr.copy_unit(u - UA, b_rsrc, t * b_step, stage + A_ELEMS, wave_u, lane);
+        else sbk.copy_unit(u - UA, b_rsrc, t * b_step, stage + A_ELEMS, wave_u, lane);
     };
     auto copy_tile = [&](int t, double *stage) {
         sa.copy(a_rsrc, t * a_step, stage, wave_u, lane);
@@ -700,7 +709,7 @@ __global__ __launch_bounds__(WM *WN * 64, 2) void k_gemm_f64r(GemmArgs<double> g
     constexpr int ISTRIDE = AM * 8, AKS = 4 * PA * 8;
     constexpr int JSTRIDE = BLAY == 1 ? 16 * BK * 8 : BNW * 8, BKS = BLAY == 1 ? 0 : 4 * PB * 8;
     auto b_base = [&](uint32_t stage_off, int ks) -> uint32_t { return BLAY == 1 ? b_addr + stage_off + (swz8 ^ (uint32_t)(ks * 32)) : b_addr + stage_off; };
-    auto nothing = [](auto) {};
+    auto nothing = [](auto) -> void {};
 
     // prologue: tile 0 by everyone; tile 1 by the older half now, by the younger half inside sub-step 0 of tile 0 (its regular slot)
     copy_tile(0, smem);
@@ -716,32 +725,32 @@ __global__ __launch_bounds__(WM *WN * 64, 2) void k_gemm_f64r(GemmArgs<double> g
         const int s_nxt = s_cur == NSTAGE - 1 ? 0 : s_cur + 1, s_prv = s_cur == 0 ? NSTAGE - 1 : s_cur - 1;
         const uint32_t cur_off = (uint32_t)(s_cur * STAGE * 8), nxt_off = (uint32_t)(s_nxt * STAGE * 8);
         {   // sub-step 0; younger half: its copies of tile it + 1 (stage free since the barrier of tile it - 1)
-            const bool go = !early && it + 1 < nk;
+            const bool go = !(DBG & 1) && !early && it + 1 < nk;
             double *dst = smem + s_nxt * STAGE;
-            asm_read_b<TN, 1 * BKS, JSTRIDE>(fb[1], b_base(cur_off, 1), std::make_integer_sequence<int, TN>{});
-            asm_groups_c<TM, TN, 1 * AKS, ISTRIDE>(acc, fa, fb[0], a_addr + cur_off, [&](auto ic) {
+            if constexpr (!(DBG & 4)) asm_read_b<TN, 1 * BKS, JSTRIDE>(fb[1], b_base(cur_off, 1), std::make_integer_sequence<int, TN>{});
+            asm_groups_c<DBG, TM, TN, 1 * AKS, ISTRIDE>(acc, fa, fb[0], a_addr + cur_off, [&](auto ic) -> void {
                 constexpr int I = decltype(ic)::value;
-                if constexpr (I >= 1 && I - 1 < NUNITS) { if (go) copy_unit(std::integral_constant<int, I - 1>{}, it + 1, dst); }
+                if constexpr (I >= 1 && I - 1 < NUNITS) { if (go) copy_unit(I - 1, it + 1, dst); }
             }, std::make_integer_sequence<int, TM>{});
         }
         {
-            asm_read_b<TN, 2 * BKS, JSTRIDE>(fb[0], b_base(cur_off, 2), std::make_integer_sequence<int, TN>{});
-            asm_groups_c<TM, TN, 2 * AKS, ISTRIDE>(acc, fa, fb[1], a_addr + cur_off, nothing, std::make_integer_sequence<int, TM>{});
+            if constexpr (!(DBG & 4)) asm_read_b<TN, 2 * BKS, JSTRIDE>(fb[0], b_base(cur_off, 2), std::make_integer_sequence<int, TN>{});
+            asm_groups_c<DBG, TM, TN, 2 * AKS, ISTRIDE>(acc, fa, fb[1], a_addr + cur_off, nothing, std::make_integer_sequence<int, TM>{});
         }
         {
-            asm_read_b<TN, 3 * BKS, JSTRIDE>(fb[1], b_base(cur_off, 3), std::make_integer_sequence<int, TN>{});
-            asm_groups_c<TM, TN, 3 * AKS, ISTRIDE>(acc, fa, fb[0], a_addr + cur_off, nothing, std::make_integer_sequence<int, TM>{});
+            if constexpr (!(DBG & 4)) asm_read_b<TN, 3 * BKS, JSTRIDE>(fb[1], b_base(cur_off, 3), std::make_integer_sequence<int, TN>{});
+            asm_groups_c<DBG, TM, TN, 3 * AKS, ISTRIDE>(acc, fa, fb[0], a_addr + cur_off, nothing, std::make_integer_sequence<int, TM>{});
             // tile it + 1 has landed in its stage (this wave's copies: vmcnt(0); everyone's: the barrier); every wave that passes has
             // finished reading tile it - 1.  The fragment reads for sub-step 3 stay in flight.
-            asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+            if constexpr (!(DBG & 2)) asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
         }
         {   // sub-step 3; older half: its copies of tile it + 2 into the stage of tile it - 1
-            const bool go = early && it + 2 < nk;
+            const bool go = !(DBG & 1) && early && it + 2 < nk;
             double *dst = smem + s_prv * STAGE;
-            asm_read_b<TN, 0, JSTRIDE>(fb[0], b_base(nxt_off, 0), std::make_integer_sequence<int, TN>{});
-            asm_groups_c<TM, TN, 0, ISTRIDE>(acc, fa, fb[1], a_addr + nxt_off, [&](auto ic) {
+            if constexpr (!(DBG & 4)) asm_read_b<TN, 0, JSTRIDE>(fb[0], b_base(nxt_off, 0), std::make_integer_sequence<int, TN>{});
+            asm_groups_c<DBG, TM, TN, 0, ISTRIDE>(acc, fa, fb[1], a_addr + nxt_off, [&](auto ic) -> void {
                 constexpr int I = decltype(ic)::value;
-                if constexpr (I >= 1 && I - 1 < NUNITS) { if (go) copy_unit(std::integral_constant<int, I - 1>{}, it + 2, dst); }
+                if constexpr (I >= 1 && I - 1 < NUNITS) { if (go) copy_unit(I - 1, it + 2, dst); }
             }, std::make_integer_sequence<int, TM>{});
         }
         s_cur = s_nxt;
@@ -768,7 +777,7 @@ __global__ __launch_bounds__(WM *WN * 64, 2) void k_gemm_f64r(GemmArgs<double> g
         }
 }
 
-template <int BLAY, int ORIENT, int BM, int BN, int WM, int WN, bool MASKTAIL>
+template <int BLAY, int ORIENT, int BM, int BN, int WM, int WN, bool MASKTAIL, int DBG = 0>
 static bool launch_r(rc_context *c, const GemmArgs<double> &g) {
     constexpr int NT = WM * WN * 64;
     constexpr size_t lds = 3 * (size_t)(DirectRows<BM, 16, NT, MASKTAIL>::ELEMS + (BLAY == 0 ? DirectRows<BN, 16, NT>::ELEMS : DirectK<BN, 16, NT>::ELEMS)) * sizeof(double);
@@ -778,7 +787,7 @@ static bool launch_r(rc_context *c, const GemmArgs<double> &g) {
     const int64_t a_span = ((int64_t)256 * g.sam + g.kchunk * g.sak + 2) * 8;
     const int64_t b_span = ((int64_t)BN * g.sbn + g.kchunk * g.sbk + 2) * 8;
     if (a_span >= (1ll << 31) || b_span >= (1ll << 31) || g.sak < 0 || g.sbn < 0 || g.sbk < 0) return false;
-    auto kern = k_gemm_f64r<BLAY, ORIENT, BM, BN, WM, WN, MASKTAIL>;
+    auto kern = k_gemm_f64r<BLAY, ORIENT, BM, BN, WM, WN, MASKTAIL, DBG>;
     static bool attr_set[64] = {};
     if (!attr_set[c->device & 63]) {
         RC_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -893,6 +902,16 @@ bool gemm_f64p_launch(rc_context *c, const GemmArgs<double> &g, int alay, int bl
         static const int wide_asm = [] { const char *e = getenv("RC_GEMM_PIPE_ASM"); return e ? atoi(e) : 1; }();  // 0: the compiler-scheduled loops (k_gemm_f64d / k_gemm_f64p)
         // three-stage ring with the copies inside the MFMA stream (k_gemm_f64r); RC_GEMM_RING=0: the two-stage k_gemm_f64a
         static const int ring = [] { const char *e = getenv("RC_GEMM_RING"); return e ? atoi(e) : 1; }();
+#ifdef RC_GEMM_PIPE_DEBUG
+        {
+            static const int rdbg = [] { const char *e = getenv("RC_GEMM_RING_DBG"); return e ? atoi(e) : 0; }();
+            if (rdbg && blay == 1 && bm == 136 && bn == 256 && wm == 2 && wn == 4 && orient == 0) {
+#define RC_RDBG(D) if (rdbg == D) return launch_r<1, 0, 136, 256, 2, 4, true, D>(c, g);
+                RC_RDBG(1) RC_RDBG(2) RC_RDBG(3) RC_RDBG(4) RC_RDBG(7) RC_RDBG(8) RC_RDBG(12) RC_RDBG(5) RC_RDBG(6)
+#undef RC_RDBG
+            }
+        }
+#endif
         if (wide_asm && ring && blay == 1 && bm == 136 && bn == 256 && wm == 2 && wn == 4 && orient == 0 && launch_r<1, 0, 136, 256, 2, 4, true>(c, g)) return true;
         if (wide_asm && ring && blay == 0 && bm == 128 && bn == 256 && wm == 1 && wn == 8 && orient == 1 && launch_r<0, 1, 128, 256, 1, 8, false>(c, g)) return true;
         if (wide_asm && blay == 1 && bm == 136 && bn == 256 && wm == 2 && wn == 4 && orient == 0 && launch_a<1, 0, 136, 256, 2, 4, true>(c, g)) return true;

@@ -199,12 +199,29 @@ struct DeviceGuard {
     ~DeviceGuard() { if (prev >= 0) (void)hipSetDevice(prev); }
 };
 
+// Entry into a C-ABI call.  The outermost call of a context resets its workspace arena; a call made from INSIDE another one -- an
+// operator callback (rc_operator) that uses the library's own products on the same context -- only marks the arena and releases
+// what it took when it returns, so the temporaries of the call around it (among them the callback's operands) stay where they are.
+struct CallScope {
+    rc_context *c;
+    size_t off = 0;
+    bool outer;
+    explicit CallScope(rc_context *ctx) : c(ctx), outer(ctx->call_depth++ == 0) {
+        if (outer) c->reset_arena();
+        else off = c->arena_off;
+    }
+    ~CallScope() {
+        --c->call_depth;
+        if (!outer) c->arena_off = off;
+    }
+};
+
 template <typename F>
 rc_status guarded(rc_context *ctx, F &&f) {
     if (!ctx) return RC_INVALID_ARGUMENT;
     DeviceGuard dg(ctx->device);
     try {
-        ctx->reset_arena();
+        CallScope scope(ctx);
         f();
         hipError_t e = hipGetLastError();
         if (e != hipSuccess) fail(RC_RUNTIME_ERROR, "kernel launch failed: %s", hipGetErrorString(e));
@@ -449,19 +466,65 @@ void lq_row_id(rc_context *c, Mat<T> l, Mat<T> q, const int64_t *ind, Mat<T> x, 
 
 // B = range^H A written into `b` (any layout)
 template <typename T>
-void project(rc_context *c, Mat<T> range, Mat<T> a, Mat<T> b) {
+void project_dense(rc_context *c, Mat<T> range, Mat<T> a, Mat<T> b) {
     gemm<T>(c, 1, range.t(), a, 0, b);
 }
 
+// The operator the range finders sample: the reference implements them for ANY `Op: MatMat` / `Op: ConjMatMat`
+// (/root/reference/src/random_sampling.rs:102, :130, :222; trait contract src/types.rs:40-51, :77-81, products :58-71, :88-101).
+// Either a dense device matrix (the rc_*_f64 / _f32 entry points: one MFMA GEMM per product) or the host's callback table
+// (rc_operator, the rc_*_op_* entry points): the compositions below are written once against these three products.
+template <typename T>
+struct OpView {
+    int64_t rows = 0, cols = 0;
+    Mat<T> dense;
+    const rc_operator *cb = nullptr;
+    static OpView of(Mat<T> a) { OpView o; o.rows = a.rows; o.cols = a.cols; o.dense = a; return o; }
+    static OpView of(const rc_operator *op) {
+        RC_REQUIRE(op != nullptr && op->matmat != nullptr && op->rows >= 0 && op->cols >= 0, RC_INVALID_ARGUMENT, "rc_operator: null table / matmat or negative extent");
+        OpView o; o.rows = op->rows; o.cols = op->cols; o.cb = op; return o;
+    }
+    static rc_matrix to_c(Mat<T> m) { rc_matrix r; r.data = m.p; r.rows = m.rows; r.cols = m.cols; r.row_stride = m.rs; r.col_stride = m.cs; return r; }
+    void call(rc_context *c, rc_operator_product_fn fn, const char *what, Mat<T> x, Mat<T> y) const {
+        RC_REQUIRE(fn != nullptr, RC_INVALID_ARGUMENT, "rc_operator: this call needs the operator's %s", what);
+        RC_REQUIRE(!c->capturing, RC_INVALID_ARGUMENT, "rc_operator: callbacks cannot be recorded into a hipGraph");
+        const std::string before = c->last_error;
+        const rc_status st = fn(cb->user, c, to_c(x), to_c(y));
+        if (st != RC_OK) {
+            const std::string inner = c->last_error != before ? c->last_error : std::string();
+            fail(st, "operator callback %s (%lld x %lld -> %lld x %lld) returned status %d%s%s", what, (long long)x.rows, (long long)x.cols,
+                 (long long)y.rows, (long long)y.cols, (int)st, inner.empty() ? "" : ": ", inner.c_str());
+        }
+    }
+    // y (rows x s) = A x
+    void matmat(rc_context *c, Mat<T> x, Mat<T> y) const {
+        RC_REQUIRE(x.rows == cols && y.rows == rows && x.cols == y.cols, RC_INVALID_ARGUMENT, "matmat: shape mismatch");
+        if (cb) call(c, cb->matmat, "matmat", x, y);
+        else gemm<T>(c, 1, dense, x, 0, y);
+    }
+    // y (cols x s) = A^H x
+    void conj_matmat(rc_context *c, Mat<T> x, Mat<T> y) const {
+        RC_REQUIRE(x.rows == rows && y.rows == cols && x.cols == y.cols, RC_INVALID_ARGUMENT, "conj_matmat: shape mismatch");
+        if (cb) call(c, cb->conj_matmat, "conj_matmat", x, y);
+        else gemm<T>(c, 1, dense.t(), x, 0, y);
+    }
+    // b (k x n) = range^H A = (A^H range)^H: for the callbacks the k x n result is handed over as the n x k view of its transpose
+    // (the reference does exactly this: conj_matmat, then .t(), src/qr.rs:316-317, src/svd.rs:175-176)
+    void project(rc_context *c, Mat<T> range, Mat<T> b) const {
+        if (cb) conj_matmat(c, range, b.t());
+        else project_dense(c, range, dense, b);
+    }
+};
+
 // QRTraits::compute_from_range_estimate (/root/reference/src/qr.rs:311-323)
 template <typename T>
-void qr_from_range(rc_context *c, Mat<T> range, Mat<T> a, Mat<T> q, Mat<T> r, int64_t *ind) {
+void qr_from_range(rc_context *c, Mat<T> range, const OpView<T> &a, Mat<T> q, Mat<T> r, int64_t *ind) {
     const int64_t m = a.rows, n = a.cols, rr = range.cols, k = std::min(rr, n);
     RC_REQUIRE(range.rows == m && q.rows == m && q.cols == k && r.rows == k && r.cols == n, RC_INVALID_ARGUMENT,
                "qr_from_range_estimate: shape mismatch");
     ArenaMark mark(c);
     Mat<T> w = tmp_colmajor<T>(c, rr, n);
-    project(c, range, a, w);
+    a.project(c, range, w);
     Mat<T> qb = tmp_colmajor<T>(c, rr, k);
     qrcp_core(c, w, k, true, qb, r, ind);
     gemm<T>(c, 1, range, qb, 0, q);
@@ -469,7 +532,7 @@ void qr_from_range(rc_context *c, Mat<T> range, Mat<T> a, Mat<T> q, Mat<T> r, in
 
 // SVDTraits::compute_from_range_estimate (/root/reference/src/svd.rs:171-183)
 template <typename T>
-void svd_from_range(rc_context *c, Mat<T> range, Mat<T> a, Mat<T> u, T *s, Mat<T> vt) {
+void svd_from_range(rc_context *c, Mat<T> range, const OpView<T> &a, Mat<T> u, T *s, Mat<T> vt) {
     const int64_t m = a.rows, n = a.cols, rr = range.cols, r = std::min(rr, n);
     RC_REQUIRE(range.rows == m && u.rows == m && u.cols == r && vt.rows == r && vt.cols == n, RC_INVALID_ARGUMENT,
                "svd_from_range_estimate: shape mismatch");
@@ -478,11 +541,11 @@ void svd_from_range(rc_context *c, Mat<T> range, Mat<T> a, Mat<T> u, T *s, Mat<T
     if (rr <= n) {
         // B (rr x n, wide): its tall orientation B^T is column-major n x rr == B row-major
         Mat<T> b = tmp_rowmajor<T>(c, rr, n);
-        project(c, range, a, b);
+        a.project(c, range, b);
         svd_core(c, b.t(), true, ub, s, vt);
     } else {
         Mat<T> b = tmp_colmajor<T>(c, rr, n);
-        project(c, range, a, b);
+        a.project(c, range, b);
         svd_core(c, b, false, ub, s, vt);
     }
     gemm<T>(c, 1, range, ub, 0, u);
@@ -491,7 +554,7 @@ void svd_from_range(rc_context *c, Mat<T> range, Mat<T> a, Mat<T> u, T *s, Mat<T
 // SampleRange::sample_range_by_rank (/root/reference/src/random_sampling.rs:103-118).
 // Only the first k Householder steps influence Q[:, :k], so the factorization stops there.
 template <typename T>
-void sample_range_by_rank(rc_context *c, Mat<T> a, int64_t k, int64_t p, Mat<T> omega, uint64_t seed, Mat<T> q) {
+void sample_range_by_rank(rc_context *c, const OpView<T> &a, int64_t k, int64_t p, Mat<T> omega, uint64_t seed, Mat<T> q) {
     const int64_t m = a.rows, n = a.cols, l = k + p;
     RC_REQUIRE(k >= 0 && p >= 0, RC_INVALID_ARGUMENT, "sample_range_by_rank: negative k or p");
     const int64_t kk = std::min(k, std::min(m, l));
@@ -505,7 +568,7 @@ void sample_range_by_rank(rc_context *c, Mat<T> a, int64_t k, int64_t p, Mat<T> 
         RC_REQUIRE(omega.rows == n && omega.cols == l, RC_INVALID_ARGUMENT, "sample_range_by_rank: omega must be %lld x %lld", (long long)n, (long long)l);
     }
     Mat<T> w = tmp_colmajor<T>(c, m, l);
-    gemm<T>(c, 1, a, omega, 0, w);
+    a.matmat(c, omega, w);
     int64_t *ind = c->alloc<int64_t>((size_t)l);
     qrcp_core(c, w, kk, true, q, Mat<T>(), ind);
 }
@@ -525,7 +588,7 @@ Mat<T> orth_full(rc_context *c, Mat<T> w) {
 // iteration restarts from A Omega and only the last one is kept: for any
 // it_count >= 1 the result is QRCP(A orth(A^H orth(A Omega)))[:, :k].
 template <typename T>
-void sample_range_power(rc_context *c, Mat<T> a, int64_t k, int64_t p, int64_t it_count, Mat<T> omega, uint64_t seed, Mat<T> q) {
+void sample_range_power(rc_context *c, const OpView<T> &a, int64_t k, int64_t p, int64_t it_count, Mat<T> omega, uint64_t seed, Mat<T> q) {
     if (it_count <= 0) { sample_range_by_rank(c, a, k, p, omega, seed, q); return; }
     const int64_t m = a.rows, n = a.cols, l = k + p;
     ArenaMark mark(c);
@@ -536,17 +599,17 @@ void sample_range_power(rc_context *c, Mat<T> a, int64_t k, int64_t p, int64_t i
         RC_REQUIRE(omega.rows == n && omega.cols == l, RC_INVALID_ARGUMENT, "sample_range_power_iteration: omega must be %lld x %lld", (long long)n, (long long)l);
     }
     Mat<T> y1 = tmp_colmajor<T>(c, m, l);
-    gemm<T>(c, 1, a, omega, 0, y1);
+    a.matmat(c, omega, y1);
     // The reference's loop restarts every iteration from the first product (a shadowed variable), so exactly one
     // power step survives; RC_OPT_POWER_ITERATION_FIXED = 1 runs the it_count steps the documentation describes.
     const int64_t steps = c->opt_power_fixed ? it_count : 1;
     for (int64_t it = 0; it < steps; ++it) {
         Mat<T> q0 = orth_full(c, y1);                    // m x min(m, l)
         Mat<T> z = tmp_colmajor<T>(c, n, q0.cols);
-        gemm<T>(c, 1, a.t(), q0, 0, z);                  // conj_matmat
+        a.conj_matmat(c, q0, z);
         Mat<T> wq = orth_full(c, z);                     // n x min(n, q0.cols)
         y1 = tmp_colmajor<T>(c, m, wq.cols);
-        gemm<T>(c, 1, a, wq, 0, y1);
+        a.matmat(c, wq, y1);
     }
     const int64_t kk = std::min(k, std::min(m, y1.cols));
     RC_REQUIRE(q.rows == m && q.cols == kk, RC_INVALID_ARGUMENT, "sample_range_power_iteration: q must be %lld x %lld", (long long)m, (long long)kk);
@@ -565,7 +628,7 @@ void max_col_norm_dev(rc_context *c, Mat<T> y, T *out_dev) {
 
 // AdaptiveSampling::sample_range_adaptive (/root/reference/src/random_sampling.rs:223-274)
 template <typename T>
-void sample_range_adaptive(rc_context *c, Mat<T> a, double rel_tol_d, int64_t s, Mat<T> omegas, uint64_t seed, Mat<T> qcap,
+void sample_range_adaptive(rc_context *c, const OpView<T> &a, double rel_tol_d, int64_t s, Mat<T> omegas, uint64_t seed, Mat<T> qcap,
                            int64_t *rank_out, int64_t *hist_rank, double *hist_res, int64_t hist_cap, int64_t *hist_len) {
     const int64_t m = a.rows, n = a.cols, cap = qcap.cols;
     RC_REQUIRE(s >= 1 && qcap.rows == m, RC_INVALID_ARGUMENT, "sample_range_adaptive: bad sample_size or q buffer");
@@ -596,7 +659,7 @@ void sample_range_adaptive(rc_context *c, Mat<T> a, double rel_tol_d, int64_t s,
     T *scal = c->alloc<T>(1);
 
     next_omega(omega);
-    gemm<T>(c, 1, a, omega, 0, y);
+    a.matmat(c, omega, y);
     T mc;
     max_col_norm_dev(c, y, scal);
     read_back(c, scal, &mc, 1);
@@ -612,13 +675,13 @@ void sample_range_adaptive(rc_context *c, Mat<T> a, double rel_tol_d, int64_t s,
         }
         Mat<T> qnew = qacc.sub(0, m, r, sq);
         qrcp_core(c, y, sq, true, qnew, Mat<T>(), ind);       // pivoted QR of the block (:254)
-        gemm<T>(c, 1, qnew.t(), a, 0, bacc.sub(r, sq, 0, n));  // b = [b ; (A^H Q_new)^H] (:256-260)
+        a.project(c, qnew, bacc.sub(r, sq, 0, n));             // b = [b ; (A^H Q_new)^H] (:256-260)
         r += sq;
         next_omega(omega);
         {   // y = A Omega - q (b Omega)  (:265-266)
             Mat<T> qr_ = qacc.sub(0, m, 0, r), tt = t1.sub(0, r, 0, s);
             gemm<T>(c, 1, bacc.sub(0, r, 0, n), omega, 0, tt);
-            gemm<T>(c, 1, a, omega, 0, y);
+            a.matmat(c, omega, y);
             gemm<T>(c, -1, qr_, tt, 1, y);
         }
         max_col_norm_dev(c, y, scal);
@@ -679,7 +742,7 @@ void rsvd_id_consumers(rc_context *c, Mat<T> range, Mat<T> b, const rc_rsvd_id_o
 
 // cfg3 "rSVD + ID" without host synchronisation
 template <typename T>
-void rsvd_id(rc_context *c, Mat<T> a, int64_t k, int64_t p, Mat<T> omega, uint64_t seed, const rc_rsvd_id_out &o) {
+void rsvd_id(rc_context *c, const OpView<T> &a, int64_t k, int64_t p, Mat<T> omega, uint64_t seed, const rc_rsvd_id_out &o) {
     const int64_t m = a.rows, n = a.cols;
     RC_REQUIRE(k >= 1 && k + p <= m && k <= n, RC_INVALID_ARGUMENT, "rsvd_id: need 1 <= k, k + p <= m, k <= n");
     ArenaMark mark(c);
@@ -694,7 +757,7 @@ void rsvd_id(rc_context *c, Mat<T> a, int64_t k, int64_t p, Mat<T> omega, uint64
     Mat<T> b = tmp_rowmajor<T>(c, k, n);
     {
         ProfScope ps(c, "stage:project B=Q^H A");
-        project(c, range, a, b);
+        a.project(c, range, b);
     }
     rsvd_id_consumers(c, range, b, o);
 }
@@ -789,7 +852,7 @@ void rsvd_id_row_sharded(rc_comm *comm, rc_context *c, Mat<T> a, int64_t k, int6
     {
         ProfScope ps(c, "stage:sharded project B = sum_r range_r^H A_r (all-reduce)");
         if (b.rs != n) fill_words(c, b.p, (size_t)k * (size_t)b.rs * sizeof(T), 0u);
-        project(c, range, a, b);
+        project_dense(c, range, a, b);
         if (comm) comm_ok(rc_comm_all_reduce_sum(comm, c, b.p, (size_t)k * (size_t)b.rs, (int32_t)sizeof(T)), "all-reduce");
     }
     rsvd_id_consumers(c, range, b, o);
@@ -911,6 +974,12 @@ rc_status rc_set_stream(rc_context *ctx, void *hip_stream) {
     DeviceGuard dg(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);  // the arena may still be in use on the old stream
     ctx->stream = static_cast<hipStream_t>(hip_stream);
+    return RC_OK;
+}
+
+rc_status rc_get_stream(rc_context *ctx, void **hip_stream) {
+    if (!ctx || !hip_stream) return RC_INVALID_ARGUMENT;
+    *hip_stream = ctx->stream;
     return RC_OK;
 }
 
@@ -1196,7 +1265,7 @@ rc_status rc_invert_permutation(rc_context *ctx, const int64_t *perm, int64_t n,
         return guarded(ctx, [&] { lq_row_id<T>(ctx, from_c<T>(l), from_c<T>(q), ind, from_c<T>(x), from_c<T>(rr)); });                   \
     }                                                                                                                                    \
     rc_status rc_qr_from_range_estimate_##SUF(rc_context *ctx, rc_matrix range, rc_matrix a, rc_matrix q, rc_matrix r, int64_t *ind) {   \
-        return guarded(ctx, [&] { qr_from_range<T>(ctx, from_c<T>(range), from_c<T>(a), from_c<T>(q), from_c<T>(r), ind); });            \
+        return guarded(ctx, [&] { qr_from_range<T>(ctx, from_c<T>(range), OpView<T>::of(from_c<T>(a)), from_c<T>(q), from_c<T>(r), ind); }); \
     }                                                                                                                                    \
     rc_status rc_svd_rank_by_tolerance_##SUF(rc_context *ctx, const T *s, int64_t len, double tol, int64_t *rank) {                      \
         return guarded(ctx, [&] { svd_rank_by_tolerance<T>(ctx, s, len, tol, rank); });                                                  \
@@ -1222,7 +1291,7 @@ rc_status rc_invert_permutation(rc_context *ctx, const int64_t *perm, int64_t n,
         });                                                                                                                              \
     }                                                                                                                                    \
     rc_status rc_svd_from_range_estimate_##SUF(rc_context *ctx, rc_matrix range, rc_matrix a, rc_matrix u, T *s, rc_matrix vt) {         \
-        return guarded(ctx, [&] { svd_from_range<T>(ctx, from_c<T>(range), from_c<T>(a), from_c<T>(u), s, from_c<T>(vt)); });            \
+        return guarded(ctx, [&] { svd_from_range<T>(ctx, from_c<T>(range), OpView<T>::of(from_c<T>(a)), from_c<T>(u), s, from_c<T>(vt)); }); \
     }                                                                                                                                    \
     rc_status rc_column_id_two_sided_##SUF(rc_context *ctx, rc_matrix c, rc_matrix c_out, rc_matrix x, int64_t *row_ind) {               \
         return guarded(ctx, [&] {                                                                                                        \
@@ -1251,17 +1320,17 @@ rc_status rc_invert_permutation(rc_context *ctx, const int64_t *perm, int64_t n,
     }                                                                                                                                    \
     rc_status rc_sample_range_by_rank_##SUF(rc_context *ctx, rc_matrix a, int64_t k, int64_t p, rc_matrix omega, uint64_t seed,          \
                                             rc_matrix q) {                                                                               \
-        return guarded(ctx, [&] { sample_range_by_rank<T>(ctx, from_c<T>(a), k, p, from_c<T>(omega), seed, from_c<T>(q)); });            \
+        return guarded(ctx, [&] { sample_range_by_rank<T>(ctx, OpView<T>::of(from_c<T>(a)), k, p, from_c<T>(omega), seed, from_c<T>(q)); }); \
     }                                                                                                                                    \
     rc_status rc_sample_range_power_iteration_##SUF(rc_context *ctx, rc_matrix a, int64_t k, int64_t p, int64_t it, rc_matrix omega,     \
                                                     uint64_t seed, rc_matrix q) {                                                        \
-        return guarded(ctx, [&] { sample_range_power<T>(ctx, from_c<T>(a), k, p, it, from_c<T>(omega), seed, from_c<T>(q)); });          \
+        return guarded(ctx, [&] { sample_range_power<T>(ctx, OpView<T>::of(from_c<T>(a)), k, p, it, from_c<T>(omega), seed, from_c<T>(q)); }); \
     }                                                                                                                                    \
     rc_status rc_sample_range_adaptive_##SUF(rc_context *ctx, rc_matrix a, double rel_tol, int64_t s, rc_matrix omegas, uint64_t seed,   \
                                              rc_matrix q_cap, int64_t *rank, int64_t *hist_rank, double *hist_res, int64_t hist_cap,     \
                                              int64_t *hist_len) {                                                                        \
         return guarded(ctx, [&] {                                                                                                        \
-            sample_range_adaptive<T>(ctx, from_c<T>(a), rel_tol, s, from_c<T>(omegas), seed, from_c<T>(q_cap), rank, hist_rank,          \
+            sample_range_adaptive<T>(ctx, OpView<T>::of(from_c<T>(a)), rel_tol, s, from_c<T>(omegas), seed, from_c<T>(q_cap), rank, hist_rank, \
                                      hist_res, hist_cap, hist_len);                                                                      \
         });                                                                                                                              \
     }                                                                                                                                    \
@@ -1269,7 +1338,39 @@ rc_status rc_invert_permutation(rc_context *ctx, const int64_t *perm, int64_t n,
                                const rc_rsvd_id_out *out) {                                                                              \
         return guarded(ctx, [&] {                                                                                                        \
             RC_REQUIRE(out != nullptr, RC_INVALID_ARGUMENT, "rsvd_id: null output descriptor");                                          \
-            rsvd_id<T>(ctx, from_c<T>(a), k, p, from_c<T>(omega), seed, *out);                                                           \
+            rsvd_id<T>(ctx, OpView<T>::of(from_c<T>(a)), k, p, from_c<T>(omega), seed, *out);                                            \
+        });                                                                                                                              \
+    }                                                                                                                                    \
+    /* the same compositions over the host's operator callbacks (rc_operator) */                                                         \
+    rc_status rc_sample_range_by_rank_op_##SUF(rc_context *ctx, const rc_operator *op, int64_t k, int64_t p, rc_matrix omega,            \
+                                               uint64_t seed, rc_matrix q) {                                                             \
+        return guarded(ctx, [&] { sample_range_by_rank<T>(ctx, OpView<T>::of(op), k, p, from_c<T>(omega), seed, from_c<T>(q)); });       \
+    }                                                                                                                                    \
+    rc_status rc_sample_range_power_iteration_op_##SUF(rc_context *ctx, const rc_operator *op, int64_t k, int64_t p, int64_t it,         \
+                                                       rc_matrix omega, uint64_t seed, rc_matrix q) {                                    \
+        return guarded(ctx, [&] { sample_range_power<T>(ctx, OpView<T>::of(op), k, p, it, from_c<T>(omega), seed, from_c<T>(q)); });     \
+    }                                                                                                                                    \
+    rc_status rc_sample_range_adaptive_op_##SUF(rc_context *ctx, const rc_operator *op, double rel_tol, int64_t s, rc_matrix omegas,     \
+                                                uint64_t seed, rc_matrix q_cap, int64_t *rank, int64_t *hist_rank, double *hist_res,     \
+                                                int64_t hist_cap, int64_t *hist_len) {                                                   \
+        return guarded(ctx, [&] {                                                                                                        \
+            sample_range_adaptive<T>(ctx, OpView<T>::of(op), rel_tol, s, from_c<T>(omegas), seed, from_c<T>(q_cap), rank, hist_rank,     \
+                                     hist_res, hist_cap, hist_len);                                                                      \
+        });                                                                                                                              \
+    }                                                                                                                                    \
+    rc_status rc_qr_from_range_estimate_op_##SUF(rc_context *ctx, rc_matrix range, const rc_operator *op, rc_matrix q, rc_matrix r,      \
+                                                 int64_t *ind) {                                                                         \
+        return guarded(ctx, [&] { qr_from_range<T>(ctx, from_c<T>(range), OpView<T>::of(op), from_c<T>(q), from_c<T>(r), ind); });       \
+    }                                                                                                                                    \
+    rc_status rc_svd_from_range_estimate_op_##SUF(rc_context *ctx, rc_matrix range, const rc_operator *op, rc_matrix u, T *s,            \
+                                                  rc_matrix vt) {                                                                        \
+        return guarded(ctx, [&] { svd_from_range<T>(ctx, from_c<T>(range), OpView<T>::of(op), from_c<T>(u), s, from_c<T>(vt)); });       \
+    }                                                                                                                                    \
+    rc_status rc_rsvd_id_op_##SUF(rc_context *ctx, const rc_operator *op, int64_t k, int64_t p, rc_matrix omega, uint64_t seed,          \
+                                  const rc_rsvd_id_out *out) {                                                                           \
+        return guarded(ctx, [&] {                                                                                                        \
+            RC_REQUIRE(out != nullptr, RC_INVALID_ARGUMENT, "rsvd_id: null output descriptor");                                          \
+            rsvd_id<T>(ctx, OpView<T>::of(op), k, p, from_c<T>(omega), seed, *out);                                                      \
         });                                                                                                                              \
     }                                                                                                                                    \
     rc_status rc_rsvd_id_row_sharded_##SUF(rc_comm *comm, rc_context *ctx, rc_matrix a_local, int64_t k, int64_t p, uint64_t seed,       \

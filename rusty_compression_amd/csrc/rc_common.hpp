@@ -90,6 +90,7 @@ struct rc_context {
     // Workspace arena.  Every C-ABI call resets the bump pointer on entry; all
     // work is ordered on `stream`, so a later call may reuse the bytes of an
     // earlier one.  Growth (rare: first calls only) synchronises the stream.
+    int call_depth = 0;                 // > 0 inside a C-ABI call: a nested call (from an operator callback) must not reset the arena
     char *arena = nullptr;
     size_t arena_size = 0;
     size_t arena_off = 0;

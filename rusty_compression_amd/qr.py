@@ -114,7 +114,18 @@ class QR:
 
     @staticmethod
     def compute_from_range_estimate(range_, op) -> "QR":
-        """src/qr.rs:311-323"""
+        """src/qr.rs:311-323 (`op`: a dense matrix or an operator with conj_matmat, operator.py)"""
+        from .operator import OperatorTable, is_operator
+
+        if is_operator(op):
+            tab = OperatorTable(op)
+            rg = as_device(range_, tab.dtype)
+            m, n = op.nrows(), op.ncols()
+            k = min(rg.shape[1], n)
+            q, r = empty(m, k, rg), empty(k, n, rg)
+            ind = torch.empty(n, dtype=torch.int64, device=rg.device)
+            tab.call(_ctx(), f"rc_qr_from_range_estimate_op_{_lib.suffix(tab.dtype)}", _lib.mat(rg), tab.byref(), _lib.mat(q), _lib.mat(r), _lib.i64p(ind))
+            return QR(q, r, ind)
         a = as_device(op)
         rg = as_device(range_, a.dtype)
         m, n = a.shape

@@ -101,7 +101,18 @@ class SVD:
 
     @staticmethod
     def compute_from_range_estimate(range_, op) -> "SVD":
-        """src/svd.rs:171-183"""
+        """src/svd.rs:171-183 (`op`: a dense matrix or an operator with conj_matmat, operator.py)"""
+        from .operator import OperatorTable, is_operator
+
+        if is_operator(op):
+            tab = OperatorTable(op)
+            rg = as_device(range_, tab.dtype)
+            m, n = op.nrows(), op.ncols()
+            r = min(rg.shape[1], n)
+            u, vt = empty(m, r, rg), empty(r, n, rg)
+            s = torch.empty(r, dtype=_lib.real_dtype(tab.dtype), device=rg.device)
+            tab.call(_ctx(), f"rc_svd_from_range_estimate_op_{_lib.suffix(tab.dtype)}", _lib.mat(rg), tab.byref(), _lib.mat(u), _sptr(s), _lib.mat(vt))
+            return SVD(u, s, vt)
         a = as_device(op)
         rg = as_device(range_, a.dtype)
         m, n = a.shape

@@ -35,6 +35,20 @@ def test_both_precisions_are_declared_for_every_typed_entry_point():
 def test_struct_layout_matches_the_header():
     assert ctypes.sizeof(_lib.rc_matrix) == 40
     assert ctypes.sizeof(_lib.rc_rsvd_id_out) == 7 * 40 + 2 * 8
+    from rusty_compression_amd.operator import rc_operator
+
+    assert ctypes.sizeof(rc_operator) == 5 * 8 and rc_operator.matmat.offset == 16 and rc_operator.user.offset == 32
+
+
+def test_operator_entry_points_reject_bad_tables_without_a_gpu():
+    """rc_*_op_*: the operator-generic samplers of the reference (src/random_sampling.rs:102, :130, :222) at the C ABI."""
+    lib = _lib.lib()
+    for name in ("rc_sample_range_by_rank_op", "rc_sample_range_power_iteration_op", "rc_sample_range_adaptive_op", "rc_qr_from_range_estimate_op",
+                 "rc_svd_from_range_estimate_op", "rc_rsvd_id_op"):
+        assert hasattr(lib, name + "_f64") and hasattr(lib, name + "_f32"), name
+    none = _lib.mat(None)
+    assert lib.rc_sample_range_by_rank_op_f64(ctypes.c_void_p(None), None, ctypes.c_int64(1), ctypes.c_int64(1), none, ctypes.c_uint64(0), none) == _lib.RC_INVALID_ARGUMENT
+    assert lib.rc_get_stream(ctypes.c_void_p(None), None) == _lib.RC_INVALID_ARGUMENT
 
 
 def test_null_context_is_rejected_without_touching_a_gpu():
