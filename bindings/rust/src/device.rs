@@ -116,6 +116,29 @@ pub fn upload<A: Scalar>(ctx: &Context, view: ArrayView2<A>) -> Result<DeviceMat
     Ok(m)
 }
 
+/// Host copy of a strided device view (the operands of an operator callback): one strided gather on the device into a
+/// contiguous staging matrix (the permutation entry point with the identity index), then one transfer.
+pub fn download_view<A: Scalar>(ctx: &Context, view: rc_matrix) -> Result<Array2<A>> {
+    let (rows, cols) = (view.rows as usize, view.cols as usize);
+    let stage = DeviceMatrix::<A>::zeros(ctx, rows, cols)?;
+    if rows * cols > 0 {
+        let idx = DeviceVec::<i64>::from_slice(ctx, &(0..cols as i64).collect::<Vec<_>>())?;
+        ctx.check(unsafe { A::ffi_apply_permutation_matrix(ctx.raw(), RC_PERM_COL, view, idx.ptr as *const i64, cols as i64, stage.view()) })?;
+        ctx.synchronize()?;
+    }
+    stage.to_array()
+}
+/// The reverse: a host array into a strided device view.
+pub fn upload_into_view<A: Scalar>(ctx: &Context, src: ArrayView2<A>, view: rc_matrix) -> Result<()> {
+    let stage = upload(ctx, src)?;
+    if src.len() > 0 {
+        let idx = DeviceVec::<i64>::from_slice(ctx, &(0..src.ncols() as i64).collect::<Vec<_>>())?;
+        ctx.check(unsafe { A::ffi_apply_permutation_matrix(ctx.raw(), RC_PERM_COL, stage.view(), idx.ptr as *const i64, src.ncols() as i64, view) })?;
+        ctx.synchronize()?;
+    }
+    Ok(())
+}
+
 /// Device vector of `n` values of `T` (singular values, index arrays).
 pub struct DeviceVec<T: Copy + Default> {
     ctx: Context,
@@ -167,6 +190,14 @@ pub fn product<A: Scalar>(a: ArrayView2<A>, x: ArrayView2<A>, conj: bool) -> Res
     };
     ctx.check(st)?;
     y.to_array()
+}
+
+/// `c - a b` for host views: upload, ONE device GEMM with alpha = -1, beta = 1 (rc_gemm_*), download.
+pub fn gemm_update<A: Scalar>(a: ArrayView2<A>, b: ArrayView2<A>, c: ArrayView2<A>) -> Result<Array2<A>> {
+    let ctx = Context::current();
+    let (da, db, dc) = (upload(&ctx, a)?, upload(&ctx, b)?, upload(&ctx, c)?);
+    ctx.check(unsafe { A::ffi_gemm_minus(ctx.raw(), da.view(), db.view(), dc.view()) })?;
+    dc.to_array()
 }
 
 // A device-resident operator: the products never leave the GPU except for the (small) right-hand sides / results.

@@ -18,11 +18,15 @@
 //! * `RandomMatrix::random_gaussian` draws on the HOST from the caller's `rand::Rng` exactly as the reference does
 //!   (`src/random_matrix.rs:120-125`), so a seeded run reproduces the reference's Omega bit for bit; the samplers upload
 //!   it.  `random_matrix::random_gaussian_device` is the on-device Philox stream for callers that do not need that.
+//! * The range finders and `compute_from_range_estimate` are generic over the operator as in the reference
+//!   (`src/random_sampling.rs:102`, `:130`, `:222`): for `f32` / `f64` the library runs the algorithm and calls back for the
+//!   two products only (`operator.rs`, `rc_*_op_*`), so a custom `MatVec` operator needs no dense matrix anywhere.
 //! * `CompressionType`, `RustyCompressionError`, `Result` are the reference's (`src/lib.rs:82-87`, `src/types.rs:11-23`).
 pub mod col_interp_decomp;
 pub mod compute_svd;
 pub mod device;
 pub mod ffi;
+pub mod operator;
 pub mod permutation;
 pub(crate) mod pivoted_qr;
 pub mod qr;
@@ -49,6 +53,7 @@ pub use random_sampling::*;
 pub use row_interp_decomp::{RowID, RowIDTraits};
 pub use svd::{SVDTraits, SVD};
 pub use two_sided_interp_decomp::{TwoSidedID, TwoSidedIDTraits};
+pub use operator::{DeviceOperator, HostConjMatMat, HostMatMat};
 pub use types::RelDiff;
 
 pub use types::{c32, c64, Scalar};

@@ -42,6 +42,8 @@ pub trait Scalar:
     unsafe fn ffi_random_gaussian(ctx: *mut rc_context, out: rc_matrix, seed: u64, offset: u64) -> rc_status;
     unsafe fn ffi_matmat(ctx: *mut rc_context, a: rc_matrix, x: rc_matrix, y: rc_matrix) -> rc_status;
     unsafe fn ffi_conj_matmat(ctx: *mut rc_context, a: rc_matrix, x: rc_matrix, y: rc_matrix) -> rc_status;
+    /// c <- c - a b (rc_gemm_* with alpha = -1, beta = 1)
+    unsafe fn ffi_gemm_minus(ctx: *mut rc_context, a: rc_matrix, b: rc_matrix, c: rc_matrix) -> rc_status;
     unsafe fn ffi_rel_diff_fro(ctx: *mut rc_context, first: rc_matrix, second: rc_matrix, out: *mut Self::Real) -> rc_status;
     unsafe fn ffi_apply_permutation_matrix(ctx: *mut rc_context, mode: i32, input: rc_matrix, perm: *const i64, n: i64, out: rc_matrix) -> rc_status;
     unsafe fn ffi_pivoted_qr(ctx: *mut rc_context, a: rc_matrix, q: rc_matrix, r: rc_matrix, ind: *mut i64) -> rc_status;
@@ -67,7 +69,7 @@ pub trait Scalar:
 }
 
 macro_rules! impl_scalar {
-    ($t:ty, $real:ty, $suf:ident, $conj:expr, $abs:expr, $from_real:expr) => {
+    ($t:ty, $real:ty, $suf:ident, $conj:expr, $abs:expr, $from_real:expr, $minus_one:expr, $one:expr) => {
         paste::paste! {
         impl Scalar for $t {
             type Real = $real;
@@ -78,6 +80,7 @@ macro_rules! impl_scalar {
             unsafe fn ffi_random_gaussian(ctx: *mut rc_context, out: rc_matrix, seed: u64, offset: u64) -> rc_status { [<rc_random_gaussian_ $suf>](ctx, out, seed, offset) }
             unsafe fn ffi_matmat(ctx: *mut rc_context, a: rc_matrix, x: rc_matrix, y: rc_matrix) -> rc_status { [<rc_matmat_ $suf>](ctx, a, x, y) }
             unsafe fn ffi_conj_matmat(ctx: *mut rc_context, a: rc_matrix, x: rc_matrix, y: rc_matrix) -> rc_status { [<rc_conj_matmat_ $suf>](ctx, a, x, y) }
+            unsafe fn ffi_gemm_minus(ctx: *mut rc_context, a: rc_matrix, b: rc_matrix, c: rc_matrix) -> rc_status { [<rc_gemm_ $suf>](ctx, 0, 0, $minus_one, a, b, $one, c) }
             unsafe fn ffi_rel_diff_fro(ctx: *mut rc_context, first: rc_matrix, second: rc_matrix, out: *mut $real) -> rc_status { [<rc_rel_diff_fro_ $suf>](ctx, first, second, out) }
             unsafe fn ffi_apply_permutation_matrix(ctx: *mut rc_context, mode: i32, input: rc_matrix, perm: *const i64, n: i64, out: rc_matrix) -> rc_status { [<rc_apply_permutation_matrix_ $suf>](ctx, mode, input, perm, n, out) }
             unsafe fn ffi_pivoted_qr(ctx: *mut rc_context, a: rc_matrix, q: rc_matrix, r: rc_matrix, ind: *mut i64) -> rc_status { [<rc_pivoted_qr_ $suf>](ctx, a, q, r, ind) }
@@ -106,12 +109,12 @@ macro_rules! impl_scalar {
     };
 }
 
-impl_scalar!(f32, f32, f32, |x: f32| x, |x: f32| x.abs(), |r: f32| r);
-impl_scalar!(f64, f64, f64, |x: f64| x, |x: f64| x.abs(), |r: f64| r);
+impl_scalar!(f32, f32, f32, |x: f32| x, |x: f32| x.abs(), |r: f32| r, -1.0f32, 1.0f32);
+impl_scalar!(f64, f64, f64, |x: f64| x, |x: f64| x.abs(), |r: f64| r, -1.0f64, 1.0f64);
 #[cfg(feature = "complex")]
-impl_scalar!(c32, f32, c32, |x: c32| x.conj(), |x: c32| x.norm(), |r: f32| c32::new(r, 0.0));
+impl_scalar!(c32, f32, c32, |x: c32| x.conj(), |x: c32| x.norm(), |r: f32| c32::new(r, 0.0), rc_complex32 { re: -1.0, im: 0.0 }, rc_complex32 { re: 1.0, im: 0.0 });
 #[cfg(feature = "complex")]
-impl_scalar!(c64, f64, c64, |x: c64| x.conj(), |x: c64| x.norm(), |r: f64| c64::new(r, 0.0));
+impl_scalar!(c64, f64, c64, |x: c64| x.conj(), |x: c64| x.norm(), |r: f64| c64::new(r, 0.0), rc_complex64 { re: -1.0, im: 0.0 }, rc_complex64 { re: 1.0, im: 0.0 });
 
 /// `Apply` (reference `src/types.rs:25-29`).
 pub trait Apply<A, Lhs> {

@@ -358,3 +358,44 @@ fn test_vector_permutaiton() {
     assert_eq!(vec.apply_permutation(perm.view(), VectorPermutationMode::NOINV), ndarray::arr1(&[3.0, 1.0, 2.0]));
     assert_eq!(vec.apply_permutation(perm.view(), VectorPermutationMode::INV), ndarray::arr1(&[2.0, 3.0, 1.0]));
 }
+
+// The range finders over a custom operator (`impl<Op: MatMat<A = $scalar>> SampleRange for Op`, src/random_sampling.rs:102, :130,
+// :222).  The reference has no test of these; this one mirrors tests/cpp/reference_tests.cpp::operator_tests: an operator that
+// is ONLY a pair of matvecs (A = U V^T held as factors; `matmat` / `conj_matmat` are the traits' per-column defaults) goes through
+// rc_*_op_f64, and agrees with the same operator given as a dense array.
+struct Factored {
+    u: ndarray::Array2<f64>,
+    v: ndarray::Array2<f64>,
+}
+impl types::MatVec for Factored {
+    type A = f64;
+    fn nrows(&self) -> usize { self.u.nrows() }
+    fn ncols(&self) -> usize { self.v.nrows() }
+    fn matvec(&self, x: ndarray::ArrayView1<f64>) -> ndarray::Array1<f64> { self.u.dot(&self.v.t().dot(&x)) }
+}
+impl types::ConjMatVec for Factored {
+    fn conj_matvec(&self, x: ndarray::ArrayView1<f64>) -> ndarray::Array1<f64> { self.v.dot(&self.u.t().dot(&x)) }
+}
+impl types::MatMat for Factored {}
+impl types::ConjMatMat for Factored {}
+
+#[test]
+fn test_range_finders_over_a_matvec_only_operator() {
+    let (m, n, r, k) = (300usize, 200usize, 30usize, 12usize);
+    let mut u = f64::random_orthogonal_matrix((m, r), &mut rng("op-u"));
+    for (j, mut col) in u.axis_iter_mut(Axis(1)).enumerate() {
+        col.mapv_inplace(|x| x * 10f64.powf(-6.0 * j as f64 / (r - 1) as f64));
+    }
+    let v = f64::random_orthogonal_matrix((n, r), &mut rng("op-v"));
+    let op = Factored { u, v };
+    let dense = op.u.dot(&op.v.t());
+    let q_op = op.sample_range_by_rank(k, 8, &mut rng("omega")).unwrap();
+    let q_dense = dense.sample_range_by_rank(k, 8, &mut rng("omega")).unwrap();
+    assert!(f64::rel_diff_fro(q_op.view(), q_dense.view()) < 1E-9);
+    let svd = SVD::<f64>::compute_from_range_estimate(q_op.view(), &op).unwrap();
+    for j in 0..5 {
+        assert!((svd.get_s()[j] - 10f64.powf(-6.0 * j as f64 / (r - 1) as f64)).abs() < 1E-6);
+    }
+    let (q_ad, hist) = op.sample_range_adaptive(1E-4, 10, &mut rng("adaptive")).unwrap();
+    assert!(!hist.is_empty() && hist.last().unwrap().1 < 1E-4 && q_ad.ncols() <= 60);
+}

@@ -19,6 +19,7 @@
 #include <stdexcept>
 #include <string>
 #include <utility>
+#include <type_traits>
 #include <vector>
 
 #include "rusty_compression_amd.h"
@@ -516,6 +517,161 @@ AdaptiveResult<T> sample_range_adaptive(const DeviceMatrix<T> &op, double rel_to
                                                  &rank, hrank.data(), hres.data(), hist_cap, &hlen));
     AdaptiveResult<T> out{qcap.leading(m, rank), {}};
     for (int64_t i = 0; i < hlen; ++i) out.residuals.emplace_back((std::size_t)hrank[(std::size_t)i], hres[(std::size_t)i]);
+    return out;
+}
+
+// ---- operators: MatVec / ConjMatVec / MatMat / ConjMatMat (src/types.rs:40-101) -------------------------------------------
+// The reference implements its range finders for ANY operator (`impl<Op: MatMat<A = $scalar>> SampleRange for Op`,
+// src/random_sampling.rs:102, :130, :222; compute_from_range_estimate<Op: ConjMatMat>, src/qr.rs:311-323, src/svd.rs:171-183).
+// Here an operator is any class with
+//     int64_t nrows() const;  int64_t ncols() const;                                   MatVec::nrows / ncols
+//     void matmat(const Context &ctx, rc_matrix x, rc_matrix y) const;                 y (nrows x s) = A x     (MatMat)
+//     void conj_matmat(const Context &ctx, rc_matrix x, rc_matrix y) const;  [optional] y (ncols x s) = A^H x  (ConjMatMat)
+// x, y are strided DEVICE views; the products are enqueued on ctx (through this library or with the host's own kernels on
+// rc_get_stream).  The overloads below hand the library an rc_operator whose callbacks forward to those members; everything
+// else (Omega, pivoted QR, SVD, the adaptive loop) runs inside the library exactly as for a dense matrix.
+template <typename T> struct ApiOp;
+#define RC_API_OP(T, SUF)                                                                          \
+    template <> struct ApiOp<T> {                                                                  \
+        static constexpr auto sample_range_by_rank = rc_sample_range_by_rank_op_##SUF;             \
+        static constexpr auto sample_range_power_iteration = rc_sample_range_power_iteration_op_##SUF; \
+        static constexpr auto sample_range_adaptive = rc_sample_range_adaptive_op_##SUF;           \
+        static constexpr auto qr_from_range_estimate = rc_qr_from_range_estimate_op_##SUF;         \
+        static constexpr auto svd_from_range_estimate = rc_svd_from_range_estimate_op_##SUF;       \
+    };
+RC_API_OP(double, f64)
+RC_API_OP(float, f32)
+#undef RC_API_OP
+
+namespace detail {
+template <class Op, class = void> struct has_conj_matmat : std::false_type {};
+template <class Op>
+struct has_conj_matmat<Op, std::void_t<decltype(std::declval<const Op &>().conj_matmat(std::declval<const Context &>(), rc_matrix{}, rc_matrix{}))>> : std::true_type {};
+
+inline int32_t status_of_current_exception() {  // a callback must not unwind into C: exceptions become the status the entry point returns
+    try { throw; }
+    catch (const CompressionError &) { return RC_COMPRESSION_ERROR; }
+    catch (const LayoutError &) { return RC_LAYOUT_ERROR; }
+    catch (const PivotedQRError &) { return RC_PIVOTED_QR_ERROR; }
+    catch (const LinalgError &) { return RC_LINALG_ERROR; }
+    catch (const AssertionFailed &) { return RC_INVALID_ARGUMENT; }
+    catch (...) { return RC_RUNTIME_ERROR; }
+}
+}  // namespace detail
+
+// rc_operator of a C++ operator object (borrowed: `op` and `ctx` must outlive the call it is passed to)
+template <class Op>
+class OperatorTable {
+  public:
+    OperatorTable(const Context &ctx, const Op &op) : ctx_(&ctx), op_(&op) {
+        table_.rows = op.nrows();
+        table_.cols = op.ncols();
+        table_.matmat = &OperatorTable::matmat_cb;
+        table_.conj_matmat = detail::has_conj_matmat<Op>::value ? &OperatorTable::conj_matmat_cb : nullptr;
+        table_.user = this;
+    }
+    const rc_operator *get() const { return &table_; }
+
+  private:
+    static int32_t matmat_cb(void *user, rc_context *, rc_matrix x, rc_matrix y) {
+        auto *self = static_cast<OperatorTable *>(user);
+        try { self->op_->matmat(*self->ctx_, x, y); return RC_OK; } catch (...) { return detail::status_of_current_exception(); }
+    }
+    static int32_t conj_matmat_cb(void *user, rc_context *, rc_matrix x, rc_matrix y) {
+        auto *self = static_cast<OperatorTable *>(user);
+        try {
+            if constexpr (detail::has_conj_matmat<Op>::value) self->op_->conj_matmat(*self->ctx_, x, y);
+            return RC_OK;
+        } catch (...) { return detail::status_of_current_exception(); }
+    }
+    const Context *ctx_;
+    const Op *op_;
+    rc_operator table_{};
+};
+
+// a dense device matrix behind the operator interface (each product is the library's own GEMM on the views it is handed)
+template <typename T>
+struct DenseOperator {
+    const DeviceMatrix<T> *a;
+    int64_t nrows() const { return a->nrows(); }
+    int64_t ncols() const { return a->ncols(); }
+    void matmat(const Context &ctx, rc_matrix x, rc_matrix y) const { ctx.check(Api<T>::matmat(ctx.raw(), a->view(), x, y)); }
+    void conj_matmat(const Context &ctx, rc_matrix x, rc_matrix y) const { ctx.check(Api<T>::conj_matmat(ctx.raw(), a->view(), x, y)); }
+};
+// A = U V^H given by its factors (U: m x r, V: n x r) and never formed: two skinny GEMMs per product
+template <typename T>
+struct LowRankOperator {
+    const DeviceMatrix<T> *u, *v;
+    int64_t nrows() const { return u->nrows(); }
+    int64_t ncols() const { return v->nrows(); }
+    void matmat(const Context &ctx, rc_matrix x, rc_matrix y) const {
+        DeviceMatrix<T> t(ctx, v->ncols(), x.cols);
+        ctx.check(Api<T>::gemm(ctx.raw(), 2, 0, Scalar<T>::wire((T)1), v->view(), x, Scalar<T>::wire((T)0), t.view()));
+        ctx.check(Api<T>::gemm(ctx.raw(), 0, 0, Scalar<T>::wire((T)1), u->view(), t.view(), Scalar<T>::wire((T)0), y));
+        ctx.synchronize();  // t is freed on return
+    }
+    void conj_matmat(const Context &ctx, rc_matrix x, rc_matrix y) const {
+        DeviceMatrix<T> t(ctx, u->ncols(), x.cols);
+        ctx.check(Api<T>::gemm(ctx.raw(), 2, 0, Scalar<T>::wire((T)1), u->view(), x, Scalar<T>::wire((T)0), t.view()));
+        ctx.check(Api<T>::gemm(ctx.raw(), 0, 0, Scalar<T>::wire((T)1), v->view(), t.view(), Scalar<T>::wire((T)0), y));
+        ctx.synchronize();
+    }
+};
+
+// impl<Op: MatMat> SampleRange for Op (src/random_sampling.rs:102-121)
+template <typename T, class Op>
+DeviceMatrix<T> sample_range_by_rank(const Context &ctx, const Op &op, int64_t k, int64_t p, uint64_t seed) {
+    int64_t kk = k < op.nrows() ? k : op.nrows();
+    if (k + p < kk) kk = k + p;
+    DeviceMatrix<T> q(ctx, op.nrows(), kk);
+    OperatorTable<Op> tab(ctx, op);
+    ctx.check(ApiOp<T>::sample_range_by_rank(ctx.raw(), tab.get(), k, p, rc_matrix{nullptr, 0, 0, 0, 0}, seed, q.view()));
+    return q;
+}
+// impl<Op: MatMat + ConjMatMat> SampleRangePowerIteration for Op (src/random_sampling.rs:130-163)
+template <typename T, class Op>
+DeviceMatrix<T> sample_range_power_iteration(const Context &ctx, const Op &op, int64_t k, int64_t p, int64_t it_count, uint64_t seed) {
+    int64_t kk = k < op.nrows() ? k : op.nrows();
+    if (k + p < kk) kk = k + p;
+    if (op.ncols() < kk) kk = op.ncols();
+    DeviceMatrix<T> q(ctx, op.nrows(), kk);
+    OperatorTable<Op> tab(ctx, op);
+    ctx.check(ApiOp<T>::sample_range_power_iteration(ctx.raw(), tab.get(), k, p, it_count, rc_matrix{nullptr, 0, 0, 0, 0}, seed, q.view()));
+    return q;
+}
+// impl<Op: MatMat + ConjMatMat> AdaptiveSampling for Op (src/random_sampling.rs:222-277)
+template <typename T, class Op>
+AdaptiveResult<T> sample_range_adaptive(const Context &ctx, const Op &op, double rel_tol, int64_t sample_size, uint64_t seed, int64_t max_rank = -1) {
+    const int64_t m = op.nrows(), n = op.ncols();
+    if (max_rank < 0) max_rank = (((m < n ? m : n) + sample_size - 1) / sample_size) * sample_size;
+    DeviceMatrix<T> qcap(ctx, m, max_rank);
+    const int64_t hist_cap = max_rank / (sample_size < 1 ? 1 : sample_size) + 2;
+    std::vector<int64_t> hrank((std::size_t)hist_cap);
+    std::vector<double> hres((std::size_t)hist_cap);
+    int64_t rank = 0, hlen = 0;
+    OperatorTable<Op> tab(ctx, op);
+    ctx.check(ApiOp<T>::sample_range_adaptive(ctx.raw(), tab.get(), rel_tol, sample_size, rc_matrix{nullptr, 0, 0, 0, 0}, seed, qcap.view(), &rank, hrank.data(),
+                                              hres.data(), hist_cap, &hlen));
+    AdaptiveResult<T> out{qcap.leading(m, rank), {}};
+    for (int64_t i = 0; i < hlen; ++i) out.residuals.emplace_back((std::size_t)hrank[(std::size_t)i], hres[(std::size_t)i]);
+    return out;
+}
+// QRTraits / SVDTraits::compute_from_range_estimate<Op: ConjMatMat> (src/qr.rs:311-323, src/svd.rs:171-183)
+template <typename T, class Op>
+QR<T> qr_from_range_estimate(const Context &ctx, const DeviceMatrix<T> &range, const Op &op) {
+    const int64_t m = op.nrows(), n = op.ncols(), k = range.ncols() < n ? range.ncols() : n;
+    QR<T> out{DeviceMatrix<T>(ctx, m, k), DeviceMatrix<T>(ctx, k, n), DeviceIndex(ctx, (std::size_t)n)};
+    OperatorTable<Op> tab(ctx, op);
+    ctx.check(ApiOp<T>::qr_from_range_estimate(ctx.raw(), range.view(), tab.get(), out.q.view(), out.r.view(), out.ind.data()));
+    return out;
+}
+template <typename T, class Op>
+SVD<T> svd_from_range_estimate(const Context &ctx, const DeviceMatrix<T> &range, const Op &op) {
+    using Real = typename Scalar<T>::real;
+    const int64_t m = op.nrows(), n = op.ncols(), r = range.ncols() < n ? range.ncols() : n;
+    SVD<T> out{DeviceMatrix<T>(ctx, m, r), DeviceBuffer<Real>(ctx, (std::size_t)r), DeviceMatrix<T>(ctx, r, n)};
+    OperatorTable<Op> tab(ctx, op);
+    ctx.check(ApiOp<T>::svd_from_range_estimate(ctx.raw(), range.view(), tab.get(), out.u.view(), out.s.data(), out.vt.view()));
     return out;
 }
 

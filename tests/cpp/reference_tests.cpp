@@ -319,6 +319,55 @@ static void sharded_test(const Context &ctx) {
     });
 }
 
+// The range finders over an OPERATOR instead of a dense array (impl<Op: MatMat> SampleRange for Op, src/random_sampling.rs:102, :130, :222;
+// compute_from_range_estimate<Op: ConjMatMat>, src/qr.rs:311-323, src/svd.rs:171-183): the reference has no tests of these, the two below
+// pin the callback path of the C ABI (rc_operator) from compiled host code.
+static void operator_tests(const Context &ctx) {
+    run_test("operator_dense_matrix_behind_callbacks_equals_the_dense_entry_points_f64", [&] {
+        const int64_t m = 600, n = 400, k = 30, p = 6;
+        auto a = random_approximate_low_rank_matrix<double>(ctx, m, n, 1.0, 1e-8, seed_of("op-dense"));
+        DenseOperator<double> op{&a};
+        auto q1 = sample_range_by_rank(a, k, p, 7);
+        auto q2 = sample_range_by_rank<double>(ctx, op, k, p, 7);
+        CHECK(q1.to_host() == q2.to_host());  // bit for bit: the callbacks run the same products on the same views
+        auto qp1 = sample_range_power_iteration(a, k, p, 2, 7);
+        auto qp2 = sample_range_power_iteration<double>(ctx, op, k, p, 2, 7);
+        CHECK(qp1.to_host() == qp2.to_host());
+        auto s1 = SVD<double>::compute_from_range_estimate(q1, a);
+        auto s2 = svd_from_range_estimate<double>(ctx, q1, op);
+        CHECK(s1.s.to_host() == s2.s.to_host() && s1.vt.to_host() == s2.vt.to_host() && s1.u.to_host() == s2.u.to_host());
+        auto r1 = QR<double>::compute_from_range_estimate(q1, a);
+        auto r2 = qr_from_range_estimate<double>(ctx, q1, op);
+        CHECK(r1.ind.to_host() == r2.ind.to_host() && r1.r.to_host() == r2.r.to_host() && r1.q.to_host() == r2.q.to_host());
+        auto ad1 = sample_range_adaptive(a, 1e-5, 8, 3);
+        auto ad2 = sample_range_adaptive<double>(ctx, op, 1e-5, 8, 3);
+        CHECK(ad1.residuals == ad2.residuals && ad1.q.to_host() == ad2.q.to_host());
+    });
+    run_test("operator_factored_low_rank_never_materialised_f64", [&] {
+        const int64_t m = 900, n = 700, r = 40, k = 20, p = 8;
+        auto u = random_orthogonal_matrix<double>(ctx, m, r, seed_of("op-u"));
+        auto v = random_orthogonal_matrix<double>(ctx, n, r, seed_of("op-v"));
+        // U <- U diag(sigma), sigma from 1 down to 1e-6
+        auto uh = u.to_host();
+        for (int64_t i = 0; i < m; ++i)
+            for (int64_t j = 0; j < r; ++j) uh[(size_t)(i * r + j)] *= std::pow(10.0, -6.0 * (double)j / (double)(r - 1));
+        auto us = DeviceMatrix<double>::from_host(ctx, uh.data(), m, r);
+        LowRankOperator<double> op{&us, &v};
+        auto dense = dot_op(0, us, 1, v);  // the same operator, materialised (for comparison only)
+        auto q_op = sample_range_by_rank<double>(ctx, op, k, p, 5);
+        auto q_d = sample_range_by_rank(dense, k, p, 5);
+        CHECK((double)rel_diff_fro(q_op, q_d) <= 1e-9);  // same Omega stream, products equal to rounding
+        auto s_op = svd_from_range_estimate<double>(ctx, q_op, op).s.to_host();
+        auto s_d = SVD<double>::compute_from_range_estimate(q_d, dense).s.to_host();
+        double worst = 0;
+        for (size_t i = 0; i < s_op.size(); ++i) worst = std::fmax(worst, std::fabs(s_op[i] - s_d[i]) / s_d[0]);
+        CHECK(worst <= 1e-11);
+        for (int64_t j = 0; j < 5; ++j) CHECK(std::fabs(s_op[(size_t)j] - std::pow(10.0, -6.0 * (double)j / (double)(r - 1))) <= 1e-6);  // the leading sigma themselves
+        auto ad = sample_range_adaptive<double>(ctx, op, 1e-4, 10, 9);
+        CHECK(!ad.residuals.empty() && ad.residuals.back().second < 1e-4 && ad.q.ncols() <= 60);
+    });
+}
+
 int main() {
     Context ctx(0);
     group<double>(ctx, 100, 50, "thin");
@@ -331,6 +380,7 @@ int main() {
     group<c32>(ctx, 50, 100, "thick");
     permutation_tests(ctx);
     sharded_test(ctx);
+    operator_tests(ctx);
     std::printf("%d tests, %d failed\n", tests_run, failures);
     return failures ? 1 : 0;
 }
