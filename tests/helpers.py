@@ -83,3 +83,25 @@ def agreed_pivot_prefix(ind, r, ind_ref, r_ref, dtype):
     a, b = float(abs(r[j, j])), float(abs(r_ref[j, j]))
     assert abs(a - b) <= tie * max(a, b), f"pivot {j} differs and is not a near tie: |r_jj| {a} vs {b}"
     return j
+
+
+def greedy_pivot_slack(a, r, ind, k):
+    """How far every one of the first k pivots of A[:, ind] = Q R is from being THE largest remaining partial column norm.
+
+    Column-pivoted QR (?geqp3) picks at step j the column of largest partial norm; two correct implementations may pick
+    different columns only where the candidates tie to the accuracy the down-dated norms are kept to.  From the factorization
+    itself (R: k x n in pivoted column order) the partial norms at step j are, in f64,
+        vn_j(c)^2 = ||A[:, ind[c]]||^2 - sum_{i < j} R[i, c]^2          (c >= j),
+    and the pivot's own is |R[j, j]|.  Returns the list of (max_c vn_j(c) - |R[j, j]|) / max_c vn_j(c), j = 0 .. k-1: every entry
+    must be below the tie tolerance for every pivot -- not only the first disagreement with a reference -- to be a legitimate choice."""
+    a = np.asarray(a, dtype=np.float64)
+    r = np.asarray(r, dtype=np.float64)
+    ind = np.asarray(ind)
+    vn2 = (a[:, ind] ** 2).sum(axis=0)
+    slack = []
+    for j in range(k):
+        rest = np.sqrt(np.maximum(vn2[j:], 0.0))
+        mx = float(rest.max())
+        slack.append((mx - abs(r[j, j])) / mx if mx > 0 else 0.0)
+        vn2 = vn2 - r[j] ** 2
+    return slack

@@ -72,6 +72,28 @@ def test_row_sharded_rsvd_id_matches_the_single_gpu_pipeline(world, tmp_path):
     assert rel(qq @ r, an[:, ind] - (an[:, ind] - rq @ (rq.T @ an[:, ind]))) <= 1e-10, "Q R = (range range^T A) P"
     assert rel(c, an[:, ind[:k]] - (an[:, ind[:k]] - rq @ (rq.T @ an[:, ind[:k]]))) <= 1e-9, "C = the selected columns of the projected matrix"
     assert abs(rel(c @ z, an) - rel(cid1.c.cpu().numpy() @ cid1.z.cpu().numpy(), an)) <= 1e-8
+    # ---- against the ORACLE on the assembled matrix with the same Omega (the Philox stream of `seed`, downloaded): the sharded
+    # HIP result is held to ?geqp3 / ?gesdd of the whole problem, not only to the single-GPU HIP pipeline.
+    # Signs: the TSQR route applies LAPACK's Householder sign convention to the STACK of local factors, so rows of R / columns of
+    # the range may differ in sign from ?geqp3 of the whole sketch; everything below is sign-invariant or sign-normalised.
+    from oracle import ref_lapack as o
+    from tests.helpers import TOL
+
+    tol = TOL[np.dtype(np.float64)]
+    omega = rc.random_gaussian((n, k + p), rc.Rng(seed)).cpu().numpy()
+    oq = o.sample_range_by_rank(an, k, p, lambda shape: omega)
+    osvd = o.SVD.compute_from_range_estimate(oq, an)
+    oqr = o.QR.compute_from_range_estimate(oq, an)
+    ocid = oqr.column_id()
+    assert rel(rq @ (rq.T @ an), oq @ (oq.T @ an)) <= 1e-9, "range of the sharded sketch vs QRCP(A Omega) of the oracle"
+    assert np.abs(s - osvd.s).max() / osvd.s[0] <= 10 * tol["sval"]
+    assert rel((u * s) @ vt, osvd.to_mat()) <= 10 * tol["factor"]
+    nso = agreed_pivot_prefix(ind[:k], r, oqr.ind[:k], oqr.r, np.float64)
+    assert nso >= k - 2, f"{nso} of {k} pivots of B agree with dgeqp3 of the oracle's projection"
+    sg = np.sign(np.diag(r)[:nso]) * np.sign(np.diag(oqr.r)[:nso])
+    assert rel(r[:nso, :nso] * sg[:, None], oqr.r[:nso, :nso]) <= 100 * tol["factor"], "leading block of R up to the row signs"
+    assert rel(np.abs(np.diag(r)[:nso]), np.abs(np.diag(oqr.r)[:nso])) <= 100 * tol["factor"]
+    assert rel(c @ z, ocid.c @ ocid.z) <= 1e-8, "C Z of the sharded ID vs the oracle's"
     # the native call against the composition of one-matrix calls (same algebra, same kernels): same pivots, same factors
     for q in parts:
         assert np.array_equal(q["ind"][:k], q["comp_ind"][:k])
