@@ -98,14 +98,43 @@ struct WqCoopArgs {
     unsigned *sync;
     unsigned *sem;
     int *flag;         // certificate word of run_certified (bit 4 = aborted)
+    // ---- stages (round 3): the rows above the current step are final, so the slab shrinks as the factorization proceeds; a launch
+    // handles the steps [row0, jend) on the rows [row0, m) only -- with the column state handed over through global memory
+    int row0;          // first live row = first step of this launch (a multiple of 8); rows < row0 of wf are final
+    int jend;          // one past the last step of this launch
+    const int *pos_in; // [n] position of every column at entry (nullptr: the identity, first launch)
+    int *pos_out;      // [n] position of every column at exit (nullptr: last launch)
+    T *vn;             // [2][n] down-dated / reference partial norms (?laqp2's vn1, vn2): read at entry when pos_in != nullptr, written at exit when pos_out != nullptr
+    unsigned units;    // budget units to release (2 per workgroup that fills its CU, 1 where two share one)
 };
 
 // NE 8-row blocks per column (8 lanes per column, lane l8 holds rows l8 + 8 e), CPG columns per group.
 // Register block 0 always holds the 8-row block that contains row j: after every 8 steps the finished
 // block (final entries of R / of the reflectors) is written out and the register blocks shift down,
 // so row j sits in a register known at compile time and there is no dynamic register indexing.
+//
+// PROTOCOL INVARIANTS (who writes what, at which scope; reviewed against the code in round 3 -- keep this list and the code in step)
+//  I1  Everything that crosses workgroups is an 8-byte agent-scope relaxed atomic (write-through store / L1-bypassing load): the
+//      header words a.hdr, the candidate columns a.cols, a.sync[0..2].  Nothing else in global memory is read by a workgroup other
+//      than the one that wrote it inside one launch (a.w / a.wf / a.vn / a.pos_* are per-column data of their owner).
+//  I2  A header word is (payload << 32) | (step + 1): it validates itself, and a reader accepts a slot only when ALL five words of
+//      it carry the step it is waiting for.  Headers are double buffered by step parity; a slot of parity p is rewritten at step
+//      j + 2 only after its owner has passed the poll of step j + 1, which needed every workgroup's header of step j + 1, which
+//      every workgroup writes after it finished reading the slots of step j.
+//  I3  A candidate column is COMPLETE in memory before the header that announces it is written: every storing wave drains its own
+//      stores (s_waitcnt vmcnt(0)) -> workgroup barrier -> wave 0 writes the header.  (The barrier alone does not wait for global
+//      stores on gfx950.)  Column slots are double buffered like the headers (same argument as I2).
+//  I4  Cleared per launch, on the stream, by k_coop_gate in front: all header words (a stale word of an earlier launch at the same
+//      address must not validate), sync[0] (finished counter), sync[2]; sync[1] (abort) is written by the gate last.
+//  I5  Pivot agreement is computed redundantly from the same 5 x G words by every workgroup with the same instruction sequence,
+//      so all workgroups take the same pivot, bit for bit; the reflector is generated redundantly from the same fetched column.
+//  I6  Every spin is bounded (kSpinLimit); on expiry the abort word is set (agent scope), every workgroup leaves at its next poll,
+//      bit 4 of the certificate is raised and NOTHING of wf / jpvt / tau may be trusted (the caller falls back).
+//  I7  The budget taken by the gate (a.units) is released exactly once, by the workgroup whose arrival at sync[0] is the last.
+//  I8  Stages: a later launch reads what the earlier one wrote (wf rows >= row0, pos_out, vn) across a kernel boundary on the same
+//      stream -- no in-kernel protocol; an aborted earlier stage (flag bit 4) makes the later ones return at once.
 template <typename T, int NE, int CPG>
-__global__ __launch_bounds__(512) void k_wq_coop(WqCoopArgs<T> a) {
+__global__ __launch_bounds__(512, NE <= 4 ? 4 : 2) void k_wq_coop(WqCoopArgs<T> a) {
     constexpr int NG = 64;  // 8-lane groups per workgroup (512 threads: 256 VGPRs per lane, the slab needs 128)
     constexpr int NW = 8;
     constexpr int kNoInt = 0x7fffffff;
@@ -122,35 +151,44 @@ __global__ __launch_bounds__(512) void k_wq_coop(WqCoopArgs<T> a) {
     const int nloc = (int)((n - c0) < a.cpw ? (n - c0) : a.cpw);
     unsigned *done = a.sync, *abortw = a.sync + 1;
 
+    const int row0 = a.row0;
     const unsigned ab0 = ld_agent(abortw);
     if (ab0 == 2u) {  // the gate gave up: no budget is held, nothing to release
         if (tid == 0 && wg == 0) atomicOr(a.flag, 4);
         return;
     }
-    if (tid == 0) sh_exit = (ab0 != 0u);
+    // an earlier stage gave up (I8): take part in nothing, but release what this launch's gate took
+    const bool dead = a.pos_in != nullptr && (__hip_atomic_load(a.flag, __ATOMIC_RELAXED, RC_AGENT) & 4) != 0;
+    if (tid == 0) sh_exit = (ab0 != 0u) || dead;
 
     // ---- load the slab into registers, initial partial norms ---------------------------
     // lane l8 of a group owns the partial norms of the group's column q = l8 (l8 < CPG)
     T x[CPG][NE];
     int pos[CPG];
     T myvn1 = 0, myvn2 = 0;
+    const int mycol = c0 + g8 + NG * l8;  // meaningful for l8 < CPG
+    const bool resumed = a.pos_in != nullptr;
+    const Mat<T> src = resumed ? a.wf : a.w;  // a later stage continues on the partially factored output of the one before
 #pragma unroll
     for (int q = 0; q < CPG; ++q) {
         const int cl = g8 + NG * q;
         const bool valid = cl < nloc;
-        const T *col = a.w.p + (int64_t)(c0 + (valid ? cl : 0)) * a.w.cs;
+        const T *col = src.p + (int64_t)(c0 + (valid ? cl : 0)) * src.cs;
         T ss = 0;
 #pragma unroll
         for (int e = 0; e < NE; ++e) {
-            const int i = l8 + 8 * e;
+            const int i = row0 + l8 + 8 * e;
             x[q][e] = (valid && i < m) ? col[i] : (T)0;
             ss = fma(x[q][e], x[q][e], ss);
         }
         ss = group_sum_dpp<8>(ss);
-        if (l8 == q) myvn1 = myvn2 = sqrt(ss);
-        pos[q] = valid ? c0 + cl : -1;
+        if (l8 == q && !resumed) myvn1 = myvn2 = sqrt(ss);
+        pos[q] = valid ? (resumed ? a.pos_in[c0 + cl] : c0 + cl) : -1;
     }
-    const int mycol = c0 + g8 + NG * l8;  // meaningful for l8 < CPG
+    if (resumed && l8 < CPG && g8 + NG * l8 < nloc) {  // the norms the previous stage left (the down-dated values, not fresh ones: ?laqp2's state)
+        myvn1 = a.vn[mycol];
+        myvn2 = a.vn[n + mycol];
+    }
     __syncthreads();
     bool aborted = sh_exit != 0;
 
@@ -169,9 +207,9 @@ __global__ __launch_bounds__(512) void k_wq_coop(WqCoopArgs<T> a) {
 #else
 #define RC_TICK(k)
 #endif
-    int rdone = 0;  // rows below rdone have been written out
-    for (int r0 = 0; r0 < a.kmax && !aborted; r0 += 8) {
-    const int jend = r0 + 8 < a.kmax ? r0 + 8 : a.kmax;
+    int rdone = row0;  // rows below rdone have been written out
+    for (int r0 = row0; r0 < a.jend && !aborted; r0 += 8) {
+    const int jend = r0 + 8 < a.jend ? r0 + 8 : a.jend;
     for (int j = r0; j < jend && !aborted; ++j) {
         const int par = j & 1;
         const int lj8 = j - r0;  // row j = r0 + lj8 lives in register block 0, lane lj8
@@ -210,7 +248,7 @@ __global__ __launch_bounds__(512) void k_wq_coop(WqCoopArgs<T> a) {
             lj = sh_j[k2] > lj ? sh_j[k2] : lj;
         }
         {
-            T *slot = a.cols + ((size_t)par * G + wg) * mp + r0;  // rows r0 ... of the candidate
+            T *slot = a.cols + ((size_t)par * G + wg) * mp + (r0 - row0);  // rows r0 ... of the candidate (slot entries are relative to row0)
 #pragma unroll
             for (int q = 0; q < CPG; ++q) {
                 if (lc >= 0 && c0 + g8 + NG * q == lc) {
@@ -283,16 +321,16 @@ __global__ __launch_bounds__(512) void k_wq_coop(WqCoopArgs<T> a) {
         const int wcol = bc[0], wslot = bc[1], wpos = bc[2], colj = bc[3];
         // ---- B: fetch the pivot column (complete before its header was posted); each wave then
         //         generates the reflector redundantly (?larfg): identical arithmetic everywhere ----
-        if (tid < mp && tid >= j && tid < m) xw[tid] = ld_agent(a.cols + ((size_t)par * G + wslot) * mp + tid);
+        if (tid < mp && row0 + tid >= j && row0 + tid < m) xw[tid] = ld_agent(a.cols + ((size_t)par * G + wslot) * mp + tid);  // xw[i - row0] = row i
         __syncthreads();
         RC_TICK(3)
         T tj = 0, beta, scal = 0;
         {
             T ss = 0;
-            for (int i = j + 1 + lane; i < m; i += 64) ss = fma(xw[i], xw[i], ss);
+            for (int i = j + 1 + lane; i < m; i += 64) ss = fma(xw[i - row0], xw[i - row0], ss);
             ss = wave_sum_dpp(ss);
             const T xnorm = sqrt(ss);
-            const T alpha = xw[j];
+            const T alpha = xw[j - row0];
             beta = alpha;
             if (xnorm != (T)0) {
                 // ?lapy2: w sqrt(1 + (z / w)^2) with w = max(|alpha|, xnorm)
@@ -309,7 +347,7 @@ __global__ __launch_bounds__(512) void k_wq_coop(WqCoopArgs<T> a) {
 #pragma unroll
         for (int e = 0; e < NE; ++e) {
             const int i = r0 + l8 + 8 * e;
-            v[e] = (i < j || i >= m) ? (T)0 : (i == j) ? (T)1 : xw[i] * scal;
+            v[e] = (i < j || i >= m) ? (T)0 : (i == j) ? (T)1 : xw[i - row0] * scal;
         }
 
         // ---- C: bookkeeping, reflector application, norm down-date -------------------------
@@ -409,14 +447,20 @@ __global__ __launch_bounds__(512) void k_wq_coop(WqCoopArgs<T> a) {
                 const int i = rdone + l8 + 8 * e;
                 if (i < m) col[i] = x[q][e];
             }
+            // (positions are a permutation at every step: the entries written by the last stage that held a column are the final ones)
             if (l8 == 0) a.jpvt[pos[q]] = c0 + g8 + NG * q;
+            if (l8 == 0 && a.pos_out) a.pos_out[c0 + g8 + NG * q] = pos[q];
+        }
+        if (a.pos_out && l8 < CPG && g8 + NG * l8 < nloc) {  // hand the norms over to the next stage
+            a.vn[mycol] = myvn1;
+            a.vn[n + mycol] = myvn2;
         }
     }
     __syncthreads();
     if (tid == 0) {
-        if (aborted) atomicOr(a.flag, 4);
+        if (aborted && !dead) atomicOr(a.flag, 4);
         const unsigned old = __hip_atomic_fetch_add(done, 1u, __ATOMIC_ACQ_REL, RC_AGENT);
-        if (old == (unsigned)G - 1u) __hip_atomic_fetch_sub(a.sem, 2u * (unsigned)G, __ATOMIC_RELAXED, RC_AGENT);
+        if (old == (unsigned)G - 1u) __hip_atomic_fetch_sub(a.sem, a.units, __ATOMIC_RELAXED, RC_AGENT);
     }
 }
 
@@ -459,21 +503,21 @@ void coop_gate_launch(rc_context *c, unsigned need, unsigned *sync, unsigned lon
     hipLaunchKernelGGL(k_coop_gate, dim3(1), dim3(256), 0, c->stream, coop_semaphore(c->device), need, budget, sync, hdr, hdr_words);
 }
 
-template <typename T>
-static void coop_shape(int64_t m, int64_t n, int *ne, int *cpg, int *cpw, int *g) {
-    *ne = m <= 64 ? 8 : m <= 128 ? 16 : 32;
-    *cpg = m <= 64 ? 8 : m <= 128 ? 4 : 2;  // 64 matrix elements per lane
+// One stage: NE 8-row blocks per column in registers (the live rows [row0, m) must fit: 8 NE >= m - row0), CPG columns per 8-lane group.
+static void stage_shape(int ne, int64_t n, int *cpg, int *cpw, int *g) {
+    *cpg = ne >= 32 ? 2 : ne >= 16 ? 4 : 8;  // at most 64 matrix elements per lane; a group owns at most 8 columns (one norm owner each)
     const int64_t cap = 64 * (int64_t)*cpg;
     const int64_t wgs = (n + cap - 1) / cap;
     *g = (int)wgs;
     *cpw = (int)((n + wgs - 1) / wgs);
 }
+static int stage_ne(int64_t live_rows) { return live_rows <= 32 ? 4 : live_rows <= 64 ? 8 : live_rows <= 128 ? 16 : 32; }
 
 template <typename T>
 bool wide_coop_supported(int64_t m, int64_t n, int device) {
     if (!(m >= 2 && m <= 256 && n >= 4 * m && n >= 256)) return false;
-    int ne, cpg, cpw, g;
-    coop_shape<T>(m, n, &ne, &cpg, &cpw, &g);
+    int cpg, cpw, g;
+    stage_shape(stage_ne(m), n, &cpg, &cpw, &g);
     // (a device with few CUs -- a partitioned one -- cannot hold the launch: the non-cooperative path runs instead)
     return g >= 1 && g <= kCoopMaxWgs && n < (int64_t)1 << 30 && 2u * (unsigned)g <= coop_budget_units(device);
 }
@@ -481,35 +525,70 @@ bool wide_coop_supported(int64_t m, int64_t n, int device) {
 // w: m x n column-major input (left untouched); wf: m x n column-major output, the factorization in
 // the format of geqp3_inplace (R on/above the diagonal, the reflector below it in physical column
 // jpvt[j]); flag gets bit 4 when the kernel had to give up (wf, jpvt, tau are then garbage).
+//
+// Stages (round 3).  The rows above the current step are final, so the slab a launch has to keep in registers shrinks: the
+// factorization runs as a short sequence of launches, each on HALF the live rows' worth of steps with the smallest register
+// layout that holds the live rows -- 128 x 8192: steps 0..63 on 32 workgroups (16 blocks per column), 64..95 on 16 workgroups
+// (8 blocks), 96..127 on 16 workgroups of half a CU each (4 blocks; two share a CU) = 2816 instead of 4096 CU-steps.  The column
+// state a later stage needs besides the matrix -- positions and ?laqp2's two norm vectors -- travels through global memory, so
+// the pivots, R and the reflectors are bit for bit those of the single launch (RC_WQ_STAGES=0 runs that; test
+// test_wide_qrcp_paths_match_lapack_and_each_other compares them).
 template <typename T>
 void geqp3_wide_coop(rc_context *c, Mat<T> w, Mat<T> wf, int64_t kmax, int64_t *jpvt, T *tau, int *flag) {
     RC_REQUIRE(w.rs == 1 && wf.rs == 1 && wf.rows == w.rows && wf.cols == w.cols, RC_LAYOUT_ERROR, "geqp3_wide_coop: column-major operands required");
     const int64_t m = w.rows, n = w.cols;
     kmax = std::min(kmax, std::min(m, n));
-    int ne, cpg, cpw, g;
-    coop_shape<T>(m, n, &ne, &cpg, &cpw, &g);
     RC_REQUIRE(wide_coop_supported<T>(m, n, c->device), RC_INVALID_ARGUMENT, "geqp3_wide_coop: unsupported shape");
-    ProfScope ps(c, "op:geqp3_wide_coop %lldx%lld k=%lld wgs=%d", (long long)m, (long long)n, (long long)kmax, g);
-    WqCoopArgs<T> a;
-    a.w = w;
-    a.wf = wf;
-    a.kmax = (int)kmax;
-    a.cpw = cpw;
-    a.jpvt = jpvt;
-    a.tau = tau;
-    a.mp = 8 * ne;
-    a.hdr = c->alloc<unsigned long long>((size_t)2 * g * 5);
-    a.cols = c->alloc<T>((size_t)2 * g * a.mp);
-    a.sync = c->alloc<unsigned>(4);
-    a.sem = coop_semaphore(c->device);
-    a.flag = flag;
-    // 512 threads x up to 256 VGPRs: one workgroup fills its CU = 2 units each
-    coop_gate_launch(c, 2u * (unsigned)g, a.sync, a.hdr, 2 * g * 5);
+    static const int staged = [] { const char *e = getenv("RC_WQ_STAGES"); return e ? atoi(e) : 1; }();
+    int *pos = nullptr;
+    T *vn = nullptr;
+    int64_t row0 = 0;
+    bool first = true;
+    while (row0 < kmax) {
+        const int ne = stage_ne(m - row0);
+        // this stage runs until half of its live rows are consumed (then the next smaller layout fits), the smallest layout to the end
+        int64_t jend = kmax;
+        if (staged && ne > 4) jend = std::min<int64_t>(kmax, row0 + 4 * (int64_t)ne);
+        const bool last = jend >= kmax;
+        int cpg, cpw, g;
+        stage_shape(ne, n, &cpg, &cpw, &g);
+        ProfScope ps(c, "op:geqp3_wide_coop %lldx%lld steps %lld..%lld wgs=%d", (long long)m, (long long)n, (long long)row0, (long long)jend, g);
+        if (!last || !first) {
+            if (!pos) {
+                pos = c->alloc<int>((size_t)n);
+                vn = c->alloc<T>((size_t)2 * n);
+            }
+        }
+        WqCoopArgs<T> a;
+        a.w = w;
+        a.wf = wf;
+        a.kmax = (int)kmax;
+        a.cpw = cpw;
+        a.jpvt = jpvt;
+        a.tau = tau;
+        a.mp = 8 * ne;
+        a.hdr = c->alloc<unsigned long long>((size_t)2 * g * 5);
+        a.cols = c->alloc<T>((size_t)2 * g * a.mp);
+        a.sync = c->alloc<unsigned>(4);
+        a.sem = coop_semaphore(c->device);
+        a.flag = flag;
+        a.row0 = (int)row0;
+        a.jend = (int)jend;
+        a.pos_in = first ? nullptr : pos;
+        a.pos_out = last ? nullptr : pos;
+        a.vn = vn;
+        // 512 threads x up to 256 VGPRs: one workgroup fills its CU = 2 units; the 4-block layout is held to 128 VGPRs: 1 unit
+        a.units = (ne <= 4 ? 1u : 2u) * (unsigned)g;
+        coop_gate_launch(c, a.units, a.sync, a.hdr, 2 * g * 5);
 #define RC_COOP(NE_, CPG_) hipLaunchKernelGGL((k_wq_coop<T, NE_, CPG_>), dim3((unsigned)g), dim3(512), 0, c->stream, a)
-    if (ne == 8) RC_COOP(8, 8);
-    else if (ne == 16) RC_COOP(16, 4);
-    else RC_COOP(32, 2);
+        if (ne == 4) RC_COOP(4, 8);
+        else if (ne == 8) RC_COOP(8, 8);
+        else if (ne == 16) RC_COOP(16, 4);
+        else RC_COOP(32, 2);
 #undef RC_COOP
+        row0 = jend;
+        first = false;
+    }
 }
 
 #ifdef RC_COOP_TIMING

@@ -1298,6 +1298,44 @@ def test_wide_qrcp_paths_match_lapack_and_each_other(dtype, shape, smin):
         assert rel(o.apply_permutation_matrix(gr, gi, "COLINV"), o.apply_permutation_matrix(r[:kk], ind, "COLINV")) <= 1e-10
 
 
+_WQ_STAGES_SNIPPET = r"""
+import hashlib, sys
+import numpy as np, torch
+import rusty_compression_amd as rc
+out = []
+for dt, shape, seed in ((torch.float64, (128, 8192), 1), (torch.float64, (100, 5000), 2), (torch.float32, (128, 4096), 3), (torch.float64, (200, 3000), 4),
+                        (torch.float64, (64, 2048), 5), (torch.float64, (120, 8192), 6)):
+    a = rc.random_gaussian(shape, rc.Rng(seed), dt)
+    for rank in (None, shape[0] // 2 + 3):
+        q, r, ind = rc.pivoted_qr(a) if rank is None else rc.pivoted_qr(a, rank=rank)
+        h = hashlib.sha256()
+        for t in (q, r, ind):
+            h.update(t.contiguous().cpu().numpy().tobytes())
+        out.append(h.hexdigest())
+print("DIGESTS " + " ".join(out))
+"""
+
+
+def test_staged_wide_coop_qrcp_equals_the_single_launch_bit_for_bit():
+    """Round 3: k_wq_coop runs in shrinking stages (steps 0..63 on 32 workgroups, 64..95 on 16, 96..127 on 16 half-CU workgroups for
+    128 x 8192), the column state (positions, ?laqp2's two norm vectors) handed over through global memory.  Q, R and the permutation
+    must be bit for bit those of the single launch (RC_WQ_STAGES=0, the round-2 kernel schedule), full and truncated, f64 and f32,
+    also for row counts that are not a multiple of the stage granule -- and the staged result is the one the LAPACK comparisons of
+    test_wide_qrcp_paths_match_lapack_and_each_other hold to ?geqp3."""
+    import os
+    import subprocess
+    import sys
+
+    def digests(env):
+        res = subprocess.run([sys.executable, "-c", _WQ_STAGES_SNIPPET], env=dict(os.environ, **env), capture_output=True, text=True, timeout=600,
+                             cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+        assert res.returncode == 0, res.stdout[-1500:] + res.stderr[-1500:]
+        return [ln for ln in res.stdout.splitlines() if ln.startswith("DIGESTS ")][0].split()[1:]
+
+    staged, single = digests({"RC_WQ_STAGES": "1"}), digests({"RC_WQ_STAGES": "0"})
+    assert len(staged) == 12 and staged == single, [i for i, (x, y) in enumerate(zip(staged, single)) if x != y]
+
+
 def test_wide_coop_qrcp_ties_take_the_first_position():
     """Equal column norms everywhere: idamax semantics = lowest position first, across workgroup boundaries."""
     m, n = 16, 1024
