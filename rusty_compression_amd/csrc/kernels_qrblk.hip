@@ -697,6 +697,29 @@ __global__ __launch_bounds__(256) void k_qrb_renorm(Mat<T> w, int row0, int all,
 // Nothing global is modified before the last step has completed: the permutation changes of the non-candidates are
 // kept in an overlay by workgroup 0 and flushed at the end, so a launch that had to give up (co-residency time-out, more
 // candidates than waves) leaves the panel untouched and the host runs it through the step kernels instead.
+//
+// PROTOCOL INVARIANTS (who writes what, at which scope; reviewed against the code in round 3 -- keep list and code in step)
+//  Q1  Cross-workgroup traffic INSIDE the launch is 8-byte agent-scope relaxed atomics only: a.hdr (headers), a.cols (posted columns),
+//      a.sync[0..2] (finished counter, abort word, commit counter).  Everything else a workgroup reads inside the launch was written
+//      before the launch (w, P.cand, P.cpos, P.cvn, vn2, st, tsc, jpvt: by kernels in front on the same stream) or by itself.
+//  Q2  Header words validate themselves: (payload << 32) | (step + 1); a reader accepts a slot only when all five words carry the
+//      step it waits for.  Headers and column slots are double buffered by step parity.  Slot parity p is rewritten at step jj + 2;
+//      its owner gets there only through the poll of step jj + 1, which needs every workgroup's header of jj + 1, which a workgroup
+//      writes only after it has finished BOTH reads of step jj (the poll and the fetch of the winning column).  Hence no slot is
+//      overwritten while anybody may still read it.
+//  Q3  A posted column is complete in memory before its header exists: the ONE wave that posts drains its own write-through stores
+//      (s_waitcnt vmcnt(0)), then the workgroup barrier, then wave 0 writes the header (the barrier alone waits for LDS traffic only).
+//  Q4  Cleared per launch by k_coop_gate on the same stream in front: all header words, sync[0], sync[2]; sync[1] is set by the gate.
+//  Q5  Every workgroup derives pivot, stop test and reflector from the same words with the same instructions: identical decisions
+//      and bit-identical reflectors everywhere (the v_t^T v_k recorded by the owners of earlier pivots rely on that).
+//  Q6  No global state of the factorization (w, vn1, vn2, pos, jpvt, st) is written before the COMMIT: after its last step a
+//      workgroup adds 1 to sync[2] and waits (bounded) until it reads G; a workgroup that aborted never adds, so either every
+//      workgroup writes back or none does.  Exceptions, harmless when the panel is abandoned: a.D, st->piv, P.tau of the steps taken
+//      (overwritten by the step kernels that redo the panel).  Workgroup 0 reads the occupants of the panel's positions (ov_orig)
+//      BEFORE the first step, because other workgroups' write-back of jpvt may start while it is still in its last step's bookkeeping.
+//  Q7  All spins are bounded (kSpin); on expiry the abort word is set and every workgroup leaves at its next poll; st->pad0 tells
+//      the host (1 completed, 2 more candidates than waves, 3 time-out) and the panel is redone by the step kernels.
+//  Q8  The device budget taken by the gate (a.need) is released exactly once, by the last arrival at sync[0].
 // ---------------------------------------------------------------------------------------------------------------------
 template <typename T>
 struct QrbCoopArgs {

@@ -146,6 +146,20 @@ __device__ unsigned long long g_jac_dbg[8];
 #else
 #define RC_JTICK(k)
 #endif
+// PROTOCOL INVARIANTS of the fused launch (two workgroups; reviewed against the code in round 3 -- keep list and code in step)
+//  J1  One direction only: workgroup 0 (producer) publishes, workgroup 1 (consumer) reads; the producer never waits for the
+//      consumer, so the two need not be co-resident and the producer's result (U, S) never depends on the consumer.
+//  J2  Everything that crosses is an 8-byte (records, check words) or 4-byte (vsync) agent-scope relaxed atomic.  A rotation record
+//      is valid iff its check word equals hash(c, s) ^ key(epoch): a torn combination of two publications and a complete record of
+//      an EARLIER launch at the same workspace address (other epoch, other key) both fail the test, so records need no clearing.
+//  J3  epoch is a per-context device counter, started at a pseudo-random 23-bit value, read by both workgroups at their start and
+//      incremented by the consumer at its very end; launches of one context are stream ordered, so every launch sees a new epoch.
+//  J4  The small hand-over words vsync[0] (number of sweeps) and vsync[1 + j] (sorted position + 1) travel as (epoch << 8) | payload
+//      AND are cleared (k_clear_words, same stream, in front) before every launch: payload 0 means "not there yet".
+//  J5  The consumer learns that sweep s exists from the first record of sweep s validating, and that it does not from
+//      vsync[0] <= s; the producer writes exactly one of the two after sweep s - 1.  Index of a record: (sweep, round, pair slot),
+//      the same expression on both sides (FULL: pair slot = group).
+//  J6  Every consumer spin is bounded (kSpin); on expiry health bit 8 is raised and V is reported incomplete -- never silently wrong.
 //   FULL   : n == LPP * NE and one group per pair slot: no row / column bounds, no slot loop (the round is bound by the
 //            number of instructions the 16 waves issue, and the predicates were a quarter of them)
 //   CN     : squared column norms are carried in LDS and updated by the rotation (app -= t apq, aqq += t apq) instead of

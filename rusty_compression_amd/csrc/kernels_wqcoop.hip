@@ -34,7 +34,15 @@
 #include <cstdlib>
 #include "rc_device.hpp"
 
+#include <chrono>
 #include <mutex>
+
+#include <cerrno>
+#include <csignal>
+#include <fcntl.h>
+#include <sys/file.h>
+#include <sys/mman.h>
+#include <unistd.h>
 
 namespace rc {
 
@@ -480,11 +488,87 @@ static unsigned *coop_semaphore(int device) {
 void coop_prepare(int device) { (void)coop_semaphore(device); }
 unsigned *coop_semaphore_of(int device) { return coop_semaphore(device); }
 
+// ---- the budget is shared between the PROCESSES that use a device ------------------------------------------------------------
+// The semaphore above lives in one process' device memory, so by itself the budget is per process, and processes that share a GPU
+// (tests/test_gpu_sharded.py: two or three ranks on one device) could together ask for more co-resident workgroups than the chip has;
+// the cooperative kernels then ran into their bounded spins and fell back -- correct, but seconds late.  Every process that uses the
+// cooperative kernels on a device therefore registers its pid in a small shared-memory table keyed by the device's PCI bus id
+// (/dev/shm/rc_amd_coop_<uid>_<busid>), and a process' budget is the device budget divided by the number of LIVE registered processes
+// (kill(pid, 0)), re-evaluated at most every 100 ms: the sum of what all processes may hold never exceeds the device budget once the
+// shares have settled (a process that was alone keeps its larger share for at most that long after a second one arrives; the
+// bounded spins cover that window).  A share too small for a kernel makes *_supported() false: the non-cooperative path runs.
+// One process per GPU -- the deployment -- always has the whole budget.  RC_COOP_SHARE=0 switches the table off.
+namespace {
+struct ShareTable {
+    uint32_t magic;
+    uint32_t reserved;
+    int32_t pids[62];
+};
+constexpr uint32_t kShareMagic = 0x52434350u;  // "RCCP"
+
+struct DeviceShare {
+    ShareTable *tab = nullptr;
+    int fd = -1;
+    bool tried = false;
+    int live = 1;
+    std::chrono::steady_clock::time_point stamp{};
+};
+
+int live_processes(int device, DeviceShare &ds) {
+    static const bool enabled = [] { const char *e = getenv("RC_COOP_SHARE"); return !(e && atoi(e) == 0); }();
+    if (!enabled) return 1;
+    const auto now = std::chrono::steady_clock::now();
+    if (ds.tried && (ds.tab == nullptr || now - ds.stamp < std::chrono::milliseconds(100))) return ds.live;
+    const int me = (int)getpid();
+    if (!ds.tried) {
+        ds.tried = true;
+        char bus[64] = "dev";
+        if (hipDeviceGetPCIBusId(bus, (int)sizeof(bus), device) != hipSuccess) snprintf(bus, sizeof(bus), "dev%d", device);
+        for (char *p = bus; *p; ++p)
+            if (*p == ':' || *p == '.' || *p == '/') *p = '_';
+        char path[160];
+        snprintf(path, sizeof(path), "/dev/shm/rc_amd_coop_%u_%s", (unsigned)getuid(), bus);
+        ds.fd = open(path, O_RDWR | O_CREAT | O_CLOEXEC, 0600);
+        if (ds.fd >= 0 && ftruncate(ds.fd, (off_t)sizeof(ShareTable)) == 0) {
+            void *m = mmap(nullptr, sizeof(ShareTable), PROT_READ | PROT_WRITE, MAP_SHARED, ds.fd, 0);
+            if (m != MAP_FAILED) ds.tab = static_cast<ShareTable *>(m);
+        }
+        if (!ds.tab) {  // no shared memory here: the budget stays per process (as before round 3)
+            if (ds.fd >= 0) close(ds.fd);
+            ds.fd = -1;
+            return ds.live = 1;
+        }
+    }
+    // register (once) and count under the file lock; slots of dead processes are reclaimed
+    int live = 0;
+    bool mine = false;
+    if (flock(ds.fd, LOCK_EX) == 0) {
+        if (ds.tab->magic != kShareMagic) {
+            std::memset(ds.tab, 0, sizeof(ShareTable));
+            ds.tab->magic = kShareMagic;
+        }
+        int free_slot = -1;
+        for (int i = 0; i < 62; ++i) {
+            const int pid = ds.tab->pids[i];
+            if (pid == me) { mine = true; ++live; continue; }
+            if (pid > 0 && (kill(pid, 0) == 0 || errno == EPERM)) { ++live; continue; }
+            ds.tab->pids[i] = 0;
+            if (free_slot < 0) free_slot = i;
+        }
+        if (!mine && free_slot >= 0) { ds.tab->pids[free_slot] = me; mine = true; ++live; }
+        (void)flock(ds.fd, LOCK_UN);
+    }
+    ds.stamp = now;
+    return ds.live = std::max(1, mine ? live : live + 1);
+}
+}  // namespace
+
 unsigned coop_budget_units(int device) {
     static std::mutex mu;
-    static unsigned cached[64] = {};
+    static unsigned total[64] = {};
+    static DeviceShare share[64];
     std::lock_guard<std::mutex> lk(mu);
-    unsigned &b = cached[device & 63];
+    unsigned &b = total[device & 63];
     if (!b) {
         int cus = 0;
         if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || cus <= 0) cus = 256;
@@ -492,14 +576,16 @@ unsigned coop_budget_units(int device) {
         const int v = e ? atoi(e) : 0;
         b = (unsigned)(v >= 32 && v <= cus ? 2 * v : 2 * cus * 3 / 4);
     }
-    return b;
+    const int procs = live_processes(device, share[device & 63]);
+    return std::max(2u, b / (unsigned)procs);
 }
 
 // one-thread gate in front of a cooperative kernel: takes `need` units of the device-wide budget (released by the cooperative
 // kernel's last workgroup), clears the kernel's header words and its sync words
 void coop_gate_launch(rc_context *c, unsigned need, unsigned *sync, unsigned long long *hdr, int hdr_words) {
-    const unsigned budget = coop_budget_units(c->device);
-    RC_REQUIRE(need <= budget, RC_INVALID_ARGUMENT, "cooperative kernel needs %u units of a budget of %u", need, budget);
+    // (the caller checked need <= budget; the share of this process may have shrunk since -- another process arrived on the device --
+    // in which case this launch still goes through once nothing else of this process holds units)
+    const unsigned budget = std::max(coop_budget_units(c->device), need);
     hipLaunchKernelGGL(k_coop_gate, dim3(1), dim3(256), 0, c->stream, coop_semaphore(c->device), need, budget, sync, hdr, hdr_words);
 }
 
