@@ -644,7 +644,84 @@ void trsm_upper(rc_context *c, Mat<T> t, Mat<T> b) {
     hipLaunchKernelGGL(k_trsm_upper<T>, dim3((unsigned)cdiv(b.cols, 256)), dim3(256), 0, c->stream, t, b);
 }
 
+// ---------------------------------------------------------------------------
+// Column ID straight from the factored working matrix (the unit of work of batches, QR::compute_from -> compress(RANK(k)) ->
+// column_id, /root/reference/src/qr.rs:270-309, examples/interpolative_decomposition.rs:25-32) in TWO launches:
+//   Z = [I | R11^-1 R12] P^T : k_id_z -- k_trsm_upper's blocked back substitution (same tiles, same order of operations: the same
+//       bits) with the triangle and the right-hand sides read from the ?geqp3-format matrix through jpvt and every solved column
+//       written to its FINAL place z[:, jpvt[p]] (apply_permutation(COLINV) folded in; no R copy, no identity fill, no inverse
+//       permutation, no gather);
+//   C = Q R11 = (A P)[:, :k] : the selected columns of A themselves (gather_cols of the ORIGINAL matrix) -- the reference forms
+//       the product Q R11, which equals those columns up to rounding (src/qr.rs:287-288 "first_part"); forming Q (?orgqr: three
+//       GEMMs per panel) only to multiply it back with R11 was a third of the launches of a cfg5 matrix.
+// ---------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void k_id_z(Mat<T> w, const int64_t *jpvt, int64_t k, Mat<T> z) {
+    constexpr int NB = 16;
+    __shared__ T tile[NB][NB + 1];
+    const int64_t n = w.cols;
+    const int64_t p = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;  // position in the pivoted order
+    const bool inside = p < n;
+    const int64_t dc = inside ? jpvt[p] : 0;                            // where column p of [I | R11^-1 R12] goes
+    const bool active = inside && p >= k;                               // a right-hand side (the first k columns are the identity)
+    const T *bcol = w.p + dc * w.cs;                                    // R12[:, p] = rows 0 .. k-1 of the physical column
+    const int64_t nblk = (k + NB - 1) / NB;
+    const int ti = threadIdx.x / NB, tj = threadIdx.x % NB;
+    if (inside && p < k)
+        for (int64_t i = 0; i < k; ++i) z.at(i, dc) = (i == p) ? (T)1 : (T)0;
+    for (int64_t bi = nblk - 1; bi >= 0; --bi) {
+        const int64_t r0 = bi * NB;
+        T acc[NB];
+#pragma unroll
+        for (int ii = 0; ii < NB; ++ii) acc[ii] = (active && r0 + ii < k) ? bcol[r0 + ii] : (T)0;
+        for (int64_t bj = nblk - 1; bj >= bi; --bj) {
+            const int64_t c0 = bj * NB;
+            __syncthreads();
+            {
+                const int64_t i = r0 + ti, l = c0 + tj;
+                tile[ti][tj] = (i < k && l < k && i <= l) ? w.p[jpvt[l] * w.cs + i] : (T)0;
+            }
+            __syncthreads();
+            if (bj > bi) {
+                T x[NB];
+#pragma unroll
+                for (int jj = 0; jj < NB; ++jj) x[jj] = (active && c0 + jj < k) ? z.at(c0 + jj, dc) : (T)0;  // this thread's own finished block
+#pragma unroll
+                for (int jj = 0; jj < NB; ++jj)
+#pragma unroll
+                    for (int ii = 0; ii < NB; ++ii) acc[ii] -= tile[ii][jj] * x[jj];
+            } else {
+#pragma unroll
+                for (int ii = NB - 1; ii >= 0; --ii) {
+                    if (r0 + ii < k) {
+                        acc[ii] /= tile[ii][ii];
+#pragma unroll
+                        for (int i2 = 0; i2 < ii; ++i2) acc[i2] -= tile[i2][ii] * acc[ii];
+                    }
+                }
+            }
+        }
+        if (active) {
+#pragma unroll
+            for (int ii = 0; ii < NB; ++ii)
+                if (r0 + ii < k) z.at(r0 + ii, dc) = acc[ii];
+        }
+    }
+}
+// a: the original m x n matrix (any layout); w: its factorization in the ?geqp3 format (column-major, columns in place, k steps);
+// jpvt: position -> physical column; cm: m x k, z: k x n
+template <typename T>
+void column_id_from_qrcp(rc_context *c, Mat<T> a, Mat<T> w, int64_t k, const int64_t *jpvt, Mat<T> cm, Mat<T> z) {
+    RC_REQUIRE(w.rs == 1 && a.rows == w.rows && a.cols == w.cols && cm.rows == a.rows && cm.cols == k && z.rows == k && z.cols == a.cols && k <= std::min(a.rows, a.cols),
+               RC_INVALID_ARGUMENT, "column_id_from_qrcp: shape mismatch");
+    if (a.cols == 0 || k == 0) return;
+    ProfScope ps(c, "op:column_id_from_qrcp %lldx%lld k=%lld", (long long)a.rows, (long long)a.cols, (long long)k);
+    hipLaunchKernelGGL(k_id_z<T>, dim3((unsigned)cdiv(a.cols, 256)), dim3(256), 0, c->stream, w, jpvt, k, z);
+    gather_cols(c, a, jpvt, cm);  // C[:, i] = A[:, jpvt[i]], i < k
+}
+
 #define RC_INST(T)                                                                                         \
+    template void column_id_from_qrcp<T>(rc_context *, Mat<T>, Mat<T>, int64_t, const int64_t *, Mat<T>, Mat<T>); \
     template void geqp3_inplace<T>(rc_context *, Mat<T>, int64_t, bool, int64_t *, T *, T *);             \
     template void extract_r<T>(rc_context *, Mat<T>, const int64_t *, Mat<T>);                             \
     template void form_q<T>(rc_context *, Mat<T>, const int64_t *, const T *, int64_t, Mat<T>);           \

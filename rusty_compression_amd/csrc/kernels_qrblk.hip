@@ -1306,6 +1306,7 @@ struct BlockedQrcpJob {
     // cooperative panels (k_qrb_coop)
     QrbCoopArgs<T> coop;
     bool coop_ready = false, coop_issued = false;
+    bool keep_t = true;  // the panels' T factors are kept for qrb_form_q (false: the caller needs no Q -- column_id_from_qrcp)
     int coop_fallbacks = 0;
     int64_t cw_issued = 0;
     unsigned grid_a = 0, grid_c = 0;
@@ -1326,8 +1327,8 @@ BlockedQrcpJob<T> *qrb_begin(rc_context *c, Mat<T> w, int64_t kmax, int64_t *jpv
     J->is_cand = c->alloc<unsigned char>((size_t)n);
     J->vn1 = c->alloc<T>((size_t)n);
     J->vn2 = c->alloc<T>((size_t)n);
-    J->Fm = c->alloc<T>((size_t)n * kNB);
-    J->Tm = c->alloc<T>((size_t)kNB * kNB);
+    J->Fm = c->alloc<T>((size_t)n * kNB + (size_t)kNB * kNB);  // F and T in one allocation: one clearing launch
+    J->Tm = J->Fm + (size_t)n * kNB;
     J->auxv = c->alloc<T>(kNB);
     J->tsc = c->alloc<T>(4);
     QrbPanel<T> &P = J->P;
@@ -1350,8 +1351,8 @@ BlockedQrcpJob<T> *qrb_begin(rc_context *c, Mat<T> w, int64_t kmax, int64_t *jpv
         c->pinned_size = 1 << 16;
     }
     J->host_st = reinterpret_cast<QrbState *>(c->pinned);
-    fill_words(c, J->Fm, (size_t)n * kNB * sizeof(T), 0u);  // whole F rows are read: keep them finite
-    fill_words(c, J->Tm, (size_t)kNB * kNB * sizeof(T), 0u);  // strictly lower part of T stays zero (block form-Q multiplies by the full square)
+    // whole F rows are read: keep them finite; the strictly lower part of T stays zero (block form-Q multiplies by the full square)
+    fill_words(c, J->Fm, ((size_t)n * kNB + (size_t)kNB * kNB) * sizeof(T), 0u);
     J->vec_ok = (w.cs % (16 / (int64_t)sizeof(T)) == 0 && reinterpret_cast<uintptr_t>(w.p) % 16 == 0) ? 1 : 0;
     hipLaunchKernelGGL(k_qrb_init<T>, dim3((unsigned)std::min<int64_t>(cdivb(n, 4), 8192)), dim3(256), 0, c->stream, w, jpvt, J->pos, J->vn1, J->vn2, J->flag);
     // candidate budget: about RC_QRCP_CAND_MB of column data (L2-resident across the steps of a panel), at least 4 NB columns
@@ -1530,7 +1531,7 @@ bool qrb_finish(BlockedQrcpJob<T> *J) {
                            J->vn1, J->vn2);
     }
     // a panel that the tau test ended early means the candidate set was too small for this spectrum
-    {   // keep the panel's T factor for the block form-Q
+    if (J->keep_t) {   // keep the panel's T factor for the block form-Q
         T *tsave = c->alloc<T>((size_t)kNB * kNB);
         RC_HIP(hipMemcpyAsync(tsave, J->Tm, (size_t)kNB * kNB * sizeof(T), hipMemcpyDeviceToDevice, c->stream));
         J->panels.push_back({j0, kb, tsave});
@@ -1574,6 +1575,8 @@ void qrb_form_q(BlockedQrcpJob<T> *J, Mat<T> q) {
 
 template <typename T>
 void qrb_end(BlockedQrcpJob<T> *J) { delete J; }
+template <typename T>
+void qrb_keep_t(BlockedQrcpJob<T> *J, bool keep) { J->keep_t = keep; }
 
 // w: m x n column-major working matrix (overwritten with the ?geqp3 output format: R on and above the
 // diagonal in position order, reflectors below, columns never moved); jpvt: n; tau: kmax
@@ -1584,6 +1587,7 @@ void geqp3_blocked(rc_context *c, Mat<T> w, int64_t kmax, int64_t *jpvt, T *tau,
     ArenaMark mark(c);
     BlockedQrcpJob<T> *J = qrb_begin<T>(c, w, kmax, jpvt, tau);
     struct Guard { BlockedQrcpJob<T> *j; ~Guard() { qrb_end(j); } } guard{J};
+    J->keep_t = !q_out.empty();
     for (;;) {
         qrb_issue(J);
         RC_HIP(hipStreamSynchronize(c->stream));
@@ -1600,7 +1604,8 @@ extern "C" void rc_debug_qrc_timing(unsigned long long *out) { (void)hipMemcpyFr
     template void qrb_issue<T>(BlockedQrcpJob<T> *);                                             \
     template bool qrb_finish<T>(BlockedQrcpJob<T> *);                                            \
     template void qrb_form_q<T>(BlockedQrcpJob<T> *, Mat<T>);                                    \
-    template void qrb_end<T>(BlockedQrcpJob<T> *);
+    template void qrb_end<T>(BlockedQrcpJob<T> *);                                               \
+    template void qrb_keep_t<T>(BlockedQrcpJob<T> *, bool);
 RC_INST_JOB(double)
 RC_INST_JOB(float)
 #undef RC_INST_JOB

@@ -866,6 +866,17 @@ void column_id_rank(rc_context *c, Mat<T> a, int64_t k, Mat<T> cm, Mat<T> z, int
     ArenaMark mark(c);
     Mat<T> w = tmp_colmajor<T>(c, m, n);
     copy_mat(c, a, w);
+    static const bool long_way = [] { const char *e = getenv("RC_COLUMN_ID_FORM_Q"); return e && atoi(e) != 0; }();
+    // Fast path: the truncated blocked factorization leaves w in the ?geqp3 format; Z and C come straight from it (column_id_from_qrcp,
+    // kernels_qr.hip: C = Q R11 is the selected columns of A themselves -- no Q is formed).  The other factorization paths
+    // (tall-skinny, short-wide, under capture) return Q and R and go through qr_column_id.
+    if (!long_way && k < n && c->opt_blocked && !c->capturing && geqp3_blocked_supported<T>(m, n, k) &&
+        !(c->opt_tsqr && tsqr_supported<T>(m, n)) && !(c->opt_wide_coop && wide_coop_supported<T>(m, n, c->device)) && !(c->opt_wide_lazy && wide_lazy_supported<T>(m, n))) {
+        T *tau = c->alloc<T>((size_t)std::max<int64_t>(k, 1));
+        geqp3_blocked<T>(c, w, k, col_ind, tau, Mat<T>());
+        column_id_from_qrcp(c, a, w, k, col_ind, cm, z);
+        return;
+    }
     Mat<T> q = tmp_colmajor<T>(c, m, k);
     Mat<T> r = tmp_rowmajor<T>(c, k, n);
     qrcp_core(c, w, k, true, q, r, col_ind);

@@ -52,8 +52,11 @@ Mat<T> tmp_cm(rc_context *c, int64_t rows, int64_t cols) {
 
 // column ID from the factorization in the ?geqp3 output format (same steps as column_id_rank in rc_api.hip)
 template <typename T>
-void finish_column_id(rc_context *c, Mat<T> w, int64_t k, const T *tau, int64_t *ind, Mat<T> cm, Mat<T> z, BlockedQrcpJob<T> *job) {
+void finish_column_id(rc_context *c, Mat<T> a, Mat<T> w, int64_t k, const T *tau, int64_t *ind, Mat<T> cm, Mat<T> z, BlockedQrcpJob<T> *job) {
     const int64_t m = w.rows, n = w.cols;
+    // RC_COLUMN_ID_FORM_Q=1: C as the product Q R11 with Q formed from the reflectors (the round-2 path, kept for comparison)
+    static const bool long_way = [] { const char *e = getenv("RC_COLUMN_ID_FORM_Q"); return e && atoi(e) != 0; }();
+    if (!long_way && k < n) { column_id_from_qrcp(c, a, w, k, ind, cm, z); return; }
     Mat<T> r = rowmajor(c->alloc<T>((size_t)k * even_ld(n)), k, n, even_ld(n));
     extract_r(c, w, ind, r);
     Mat<T> q = tmp_cm<T>(c, m, k);
@@ -134,7 +137,7 @@ void batch_column_id(rc_context *const *ctxs, int nctx, const rc_matrix *mats, i
         char *base = slot(ln.idx);
         Mat<T> cm = rowmajor(reinterpret_cast<T *>(base), m, k, k);
         Mat<T> z = rowmajor(reinterpret_cast<T *>(base) + (size_t)m * k, k, n, n);
-        finish_column_id<T>(ln.c, ln.w, k, ln.tau, ln.ind, cm, z, ln.job);
+        finish_column_id<T>(ln.c, from_c<T>(mats[ln.idx]), ln.w, k, ln.tau, ln.ind, cm, z, ln.job);
         RC_HIP(hipMemcpyAsync(base + align8(((size_t)m * k + (size_t)k * n) * sizeof(T)), ln.ind, (size_t)n * sizeof(int64_t), hipMemcpyDeviceToDevice, ln.c->stream));
     };
     // set-up of the next matrix on a lane: working copy, then either the first panel of the blocked factorization (true: the
@@ -151,6 +154,8 @@ void batch_column_id(rc_context *const *ctxs, int nctx, const rc_matrix *mats, i
         copy_mat(ln.c, from_c<T>(mats[ln.idx]), ln.w);  // the reference's F-order working copy (pivoted_qr.rs:28-29)
         if (ln.c->opt_blocked && geqp3_blocked_supported<T>(m, n, k)) {
             ln.job = qrb_begin<T>(ln.c, ln.w, k, ln.ind, ln.tau);
+            static const bool long_way = [] { const char *e = getenv("RC_COLUMN_ID_FORM_Q"); return e && atoi(e) != 0; }();
+            qrb_keep_t(ln.job, long_way || k >= n);  // (the ID comes straight from the factored matrix: no Q, no T factors to keep)
             ln.active = true;
             return true;
         }

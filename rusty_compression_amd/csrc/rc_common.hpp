@@ -196,6 +196,8 @@ template <typename T> void fill_identity(rc_context *c, Mat<T> dst);            
 template <typename T> void fill_zero(rc_context *c, Mat<T> dst);
 template <typename T> void scale_rows(rc_context *c, const T *s, Mat<T> src, Mat<T> dst);   // dst[i,:] = s[i] * src[i,:]
 template <typename T> void gather_cols(rc_context *c, Mat<T> src, const int64_t *idx, Mat<T> dst);  // dst[:, j] = src[:, idx[j]]
+// C, Z of the rank-k column ID from the ?geqp3-format factorization w of a (kernels_qr.hip: two launches, no Q)
+template <typename T> void column_id_from_qrcp(rc_context *c, Mat<T> a, Mat<T> w, int64_t k, const int64_t *jpvt, Mat<T> cm, Mat<T> z);
 void invert_perm(rc_context *c, const int64_t *perm, int64_t n, int64_t *inv);
 void fill_words(rc_context *c, void *p, size_t bytes, unsigned v);  // every 32-bit word of [p, p + bytes) = v, by a kernel on c->stream (no hipMemset*)
 void iota_i64(rc_context *c, int64_t *p, int64_t n);
@@ -228,6 +230,7 @@ template <typename T> void qrb_issue(BlockedQrcpJob<T> *job);
 template <typename T> bool qrb_finish(BlockedQrcpJob<T> *job);
 template <typename T> void qrb_form_q(BlockedQrcpJob<T> *job, Mat<T> q);  // after completion
 template <typename T> void qrb_end(BlockedQrcpJob<T> *job);
+template <typename T> void qrb_keep_t(BlockedQrcpJob<T> *job, bool keep);  // false: no Q will be formed, the panels' T factors need not be kept
 // short-wide matrices (m <= 256 << n): read-only "lazy" pivoted QR with the explicit m x m factor
 template <typename T> bool wide_lazy_supported(int64_t m, int64_t n);
 template <typename T> void geqp3_wide_lazy(rc_context *c, Mat<T> b, int64_t kmax, int64_t *jpvt, Mat<T> q, Mat<T> r);
