@@ -546,7 +546,7 @@ def run_cfg3(args):
         # record names the kernel instantiation it was taken on, so a stale figure is detectable: it is reported only when
         # that instantiation is the one the library still launches for this shape (rc_gemm_kernel_name)
         traffic, traffic_src = None, None
-        for tname in ("r02_pmc_traffic.json", "r01_pmc_traffic.json"):
+        for tname in ("r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):
             tpath = os.path.join(ROOT, "profiles", tname)
             if not os.path.exists(tpath):
                 continue
@@ -570,8 +570,27 @@ def run_cfg3(args):
                 else:
                     traffic_src["stale"] = "PMC pass was taken on %s, the library now launches %s" % (rec.get("kernel"), cur)
             break
+        # What the TIMED REGION runs is not this lone launch: with S lanes in flight the big products are not split (32 workgroups
+        # each, the other lanes fill the chip).  Their in-flight cost comes from a kernel trace of this very command (a committed
+        # record written by tools/gpu_round3_profiles.sh, named per kernel instantiation): CU-time = duration x workgroups / 256.
+        in_flight = None
+        ipath = os.path.join(ROOT, "profiles", "r03_in_flight.json")
+        cur_name = sketch_kernel_name()
+        if os.path.exists(ipath) and cur_name:
+            try:
+                rec = json.load(open(ipath))
+                ent = [e for e in rec.get("kernels", {}).get(cur_name.replace(" ", ""), []) if e.get("workgroups", 0) < 256]
+                if ent:
+                    e = max(ent, key=lambda x: x.get("launches", 0))
+                    cu_ms = e["cu_time_us"] * 1e-3
+                    in_flight = {"kernel": cur_name, "workgroups": e["workgroups"], "launches_in_trace": e["launches"], "avg_launch_us": e["avg_us"],
+                                 "cu_time_ms": round(cu_ms, 4), "tflops_per_chip_equivalent": round(fl["sketch_gemm"] / (cu_ms * 1e-3) / 1e12, 2),
+                                 "frac": round(fl["sketch_gemm"] / (cu_ms * 1e-3) / 1e12 / F64_MFMA_PEAK_TFLOPS, 4),
+                                 "source": "profiles/r03_in_flight.json: " + rec.get("source", "")}
+            except Exception:
+                in_flight = None
         roof = {"bound": "mfma", "kernel": "%s (sketch Y = A*Omega, %dx%dx%d, run as Y^T = Omega^T A^T)" % (sketch_kernel_name() or "k_gemm_f64", m, l, n), "achieved": round(achieved, 3),
-                "peak": F64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / F64_MFMA_PEAK_TFLOPS, 4), "traffic": traffic, "traffic_source": traffic_src,
+                "peak": F64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / F64_MFMA_PEAK_TFLOPS, 4), "traffic": traffic, "traffic_source": traffic_src, "in_flight": in_flight,
                 "avg_launch_ms": round(ms_launch, 4), "gemm_ms": round(ms_gemm, 4), "splitk_reduce_ms": round(ms_reduce, 4), "launches_timed": len(samples),
                 "launch_ms_samples_before_timed_region": [round(x[key], 4) for x in prof_before if key in x],
                 "launch_ms_samples_after_timed_region": [round(x[key], 4) for x in samples_after if key in x],

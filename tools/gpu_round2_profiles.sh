@@ -33,7 +33,7 @@ for grp in "FETCH_SIZE" "WRITE_SIZE"; do
 done
 cd $R
 echo "== qrblk bench $(date +%T)" | tee -a $O/progress.log
-timeout -k 10 300 python tools/qrblk_bench.py > $O/qrblk_bench.json 2> $O/qrblk_bench.err
+timeout -k 10 300 python tools/qrblk_bench.py > $O/qrblk_bench.json 2> $O/qrblk_bench.err || { echo "qrblk_bench failed"; tail -5 $O/qrblk_bench.err; exit 1; }
 python - <<'PY'
 import csv, glob, collections, json, os
 O = 'gpurun_out/r02'
