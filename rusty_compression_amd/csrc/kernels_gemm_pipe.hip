@@ -912,8 +912,9 @@ bool gemm_f64p_launch(rc_context *c, const GemmArgs<double> &g, int alay, int bl
             }
         }
 #endif
-        if (wide_asm && ring && blay == 1 && bm == 136 && bn == 256 && wm == 2 && wn == 4 && orient == 0 && launch_r<1, 0, 136, 256, 2, 4, true>(c, g)) return true;
-        if (wide_asm && ring && blay == 0 && bm == 128 && bn == 256 && wm == 1 && wn == 8 && orient == 1 && launch_r<0, 1, 128, 256, 1, 8, false>(c, g)) return true;
+        // (RC_GEMM_RING: 1 both products, 2 the sketch only, 3 the projection only)
+        if (wide_asm && (ring == 1 || ring == 2) && blay == 1 && bm == 136 && bn == 256 && wm == 2 && wn == 4 && orient == 0 && launch_r<1, 0, 136, 256, 2, 4, true>(c, g)) return true;
+        if (wide_asm && (ring == 1 || ring == 3) && blay == 0 && bm == 128 && bn == 256 && wm == 1 && wn == 8 && orient == 1 && launch_r<0, 1, 128, 256, 1, 8, false>(c, g)) return true;
         if (wide_asm && blay == 1 && bm == 136 && bn == 256 && wm == 2 && wn == 4 && orient == 0 && launch_a<1, 0, 136, 256, 2, 4, true>(c, g)) return true;
         if (wide_asm && blay == 0 && bm == 128 && bn == 256 && wm == 1 && wn == 8 && orient == 1 && launch_a<0, 1, 128, 256, 1, 8, false>(c, g)) return true;
         if (blay == 1 && bm == 136 && bn == 128 && wm == 2 && wn == 2 && orient == 0 && launch_a<1, 0, 136, 128, 2, 2, true>(c, g)) return true;
