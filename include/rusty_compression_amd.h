@@ -124,6 +124,13 @@ rc_status rc_graph_destroy(rc_context *ctx, void *graph_exec);
  * keeps the whole matrix in registers (one grid barrier per Householder step instead of two kernel
  * launches); certifies itself like the tall-skinny path (bit 4 of the health word = its workgroups
  * could not all become resident in time) and falls back to the lazy scheme; 0 disables it. */
+/* Reproducibility.  Every entry point is deterministic: the same call with the same options on the same context state gives the
+ * same bits (no atomics on results, fixed split-K reduction order).  Two settings choose between implementations of the same
+ * factorization, and bits are promised PER SETTING, not across them: (i) RC_OPT_CONCURRENCY_HINT decides whether wide products
+ * split K (a lone launch) or not (many compressions in flight): results differ by summation order; (ii) a call recorded into a
+ * hipGraph cannot read scalars back, so general-shape pivoted QRs run the per-step chain there and the blocked panels eagerly:
+ * same pivots on the data-determined prefix, factors equal to rounding (tests: test_captured_pivoted_qr_of_a_blocked_eligible_shape…).
+ * The cfg3 pipeline (rc_rsvd_id_*) takes the same path eagerly and captured: its replays equal the eager result bit for bit. */
 /* RC_OPT_POWER_ITERATION_FIXED (default 0): rc_sample_range_power_iteration_* performs it_count power steps
  * (Y <- A orth(A^H orth(Y))) as the reference documents; 0 reproduces the reference's behaviour, where a shadowed
  * loop variable leaves exactly one step (src/random_sampling.rs:145-153). */

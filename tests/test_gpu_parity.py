@@ -1516,6 +1516,57 @@ def test_jacobi_kernel_variants_behind_the_environment_switches(env):
     assert res.returncode == 0, res.stdout + res.stderr
 
 
+@pytest.mark.parametrize("dtype,shape", [(np.float64, (512, 512)), (np.float32, (640, 384)), (np.float64, (300, 700))])
+def test_captured_pivoted_qr_of_a_blocked_eligible_shape_agrees_with_the_eager_one(dtype, shape):
+    """for shapes that are neither tall-skinny nor short-wide the EAGER call runs the blocked ?laqps panels while a call
+    under hipGraph capture runs the per-step chain (the blocked path reads one scalar back per panel): two routes to the same
+    factorization.  They are not promised to agree bit for bit (bit-reproducibility holds per setting: eager vs captured, and per
+    RC_OPT_CONCURRENCY_HINT -- include/rusty_compression_amd.h); what is promised and checked here: the same pivots on the prefix the
+    data determine, R and Q to the parity tolerance, both against ?geqp3."""
+    import ctypes
+
+    from rusty_compression_amd import _lib
+
+    lib = _lib.lib()
+    rng = np.random.default_rng(shape[0] + shape[1])
+    an = o.random_approximate_low_rank_matrix(shape, 1.0, 1e-6 if dtype == np.float64 else 1e-3, rng, dtype)
+    oq, orr, oind = o.pivoted_qr(an)
+    k = min(shape)
+    tdt = torch.float64 if dtype == np.float64 else torch.float32
+    st = torch.cuda.Stream()
+    with torch.cuda.stream(st):
+        ctx = _lib.Context(torch.cuda.current_device(), st.cuda_stream)
+        a = torch.from_numpy(an).cuda()
+        q, r = torch.empty((shape[0], k), dtype=tdt, device="cuda"), torch.empty((k, shape[1]), dtype=tdt, device="cuda")
+        ind = torch.empty(shape[1], dtype=torch.int64, device="cuda")
+        args = (_lib.mat(a), _lib.mat(q), _lib.mat(r), ctypes.c_void_p(ind.data_ptr()))
+        name = "rc_pivoted_qr_f64" if dtype == np.float64 else "rc_pivoted_qr_f32"
+        ctx.call(name, *args)
+        ctx.synchronize()
+        eq, er, ei = npy(q).copy(), npy(r).copy(), npy(ind).copy()
+        graph = ctypes.c_void_p(None)
+        ctx.check(lib.rc_graph_begin_capture(ctx._h))
+        ctx.call(name, *args)
+        ctx.check(lib.rc_graph_end_capture(ctx._h, ctypes.byref(graph)))
+        q.zero_(); r.zero_(); ind.zero_()
+        ctx.check(lib.rc_graph_launch(ctx._h, graph))
+        ctx.synchronize()
+        assert ctx.get_health() == 0
+        gq, gr, gi = npy(q), npy(r), npy(ind)
+        lib.rc_graph_destroy(ctx._h, graph)
+        ctx.close()
+    tol = TOL[np.dtype(dtype)]["factor"]
+    for tag, (fq, fr, fi) in {"eager": (eq, er, ei), "captured": (gq, gr, gi)}.items():
+        assert is_permutation(fi, shape[1]), tag
+        ns = agreed_pivot_prefix(fi, fr, oind, orr, dtype)
+        assert ns >= min(stable_prefix(orr, dtype), k) - (0 if dtype == np.float64 else 2), (tag, ns)
+        assert rel(fq @ fr, an[:, fi]) <= (1e-13 if dtype == np.float64 else 5e-6), tag
+        assert rel(fr[:ns, :ns], orr[:ns, :ns]) <= 10 * tol, tag
+    ns = agreed_pivot_prefix(gi, gr, ei, er, dtype)
+    assert ns >= min(stable_prefix(er, dtype), k) - (0 if dtype == np.float64 else 2), f"eager and captured part ways at pivot {ns}"
+    assert rel(gr[:ns, :ns], er[:ns, :ns]) <= 10 * tol and rel(gq[:, :ns], eq[:, :ns]) <= 100 * tol
+
+
 def test_graph_replay_matches_eager_and_survives_workspace_growth():
     """hipGraph capture of the fused pipeline (rc_graph_*): the replay reproduces the eager result bit
     for bit, and an eager call that outgrows the workspace afterwards must not invalidate the graph
