@@ -566,6 +566,8 @@ void c_jacobi_svd_tall(rc_context *c, CV<R> g, CV<R> uc, R *s, CV<R> vc) {
     hipLaunchKernelGGL(k_c_jacobi_rank<R>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, n, sig, order, s);
     hipLaunchKernelGGL(k_c_jacobi_emit<R>, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, c->stream, g, v, sig, order, uc, vc);
 }
+template <typename R>
+void c_colinv(rc_context *c, CV<R> in, const int64_t *ind, CV<R> out);
 // ComputeSVD::compute_svd (src/compute_svd.rs:18-27): a (m x n) = u diag(s) vt, u: m x r, vt: r x n, r = min(m, n)
 template <typename R>
 void c_compute_svd(rc_context *c, CV<R> a, CV<R> u, R *s, CV<R> vt) {
@@ -573,19 +575,45 @@ void c_compute_svd(rc_context *c, CV<R> a, CV<R> u, R *s, CV<R> vt) {
     RC_REQUIRE(u.rows == m && u.cols == r && vt.rows == r && vt.cols == n, RC_INVALID_ARGUMENT, "compute_svd: output shapes");
     if (r == 0) return;
     ArenaMark mark(c);
+    // Round 3: a clearly rectangular input goes through a QR factorization first (as ?gesdd does): the one-launch-per-round Jacobi
+    // then works on the r x r triangle instead of on M-row columns (128 x 2048 c64: 23 -> see tools/bench_complex.py)
+    const bool qr_first = std::max(m, n) >= 2 * r && r >= 2;
     if (m >= n) {
-        CV<R> g = tmp_cm<R>(c, m, n), uc = tmp_cm<R>(c, m, n), vc = tmp_cm<R>(c, n, n);
-        c_copy(c, a, g);
-        c_jacobi_svd_tall(c, g, uc, s, vc);
-        c_copy(c, uc, u);
-        c_copy(c, vc.t(), vt, true);  // vt = vc^H
+        if (qr_first) {
+            CV<R> q = tmp_cm<R>(c, m, n), rr = tmp_cm<R>(c, n, n), rp = tmp_cm<R>(c, n, n), ur = tmp_cm<R>(c, n, n), vc = tmp_cm<R>(c, n, n);
+            int64_t *ind = c->alloc<int64_t>((size_t)n);
+            c_pivoted_qr(c, a, q, rr, ind, n);   // a P = q rr
+            c_colinv(c, rr, ind, rp);            // rr P^H: a = q (rr P^H)
+            c_jacobi_svd_tall(c, rp, ur, s, vc);
+            c_gemm<R>(c, 0, 0, one<R>(), q, ur, zero<R>(), u);
+            c_copy(c, vc.t(), vt, true);
+        } else {
+            CV<R> g = tmp_cm<R>(c, m, n), uc = tmp_cm<R>(c, m, n), vc = tmp_cm<R>(c, n, n);
+            c_copy(c, a, g);
+            c_jacobi_svd_tall(c, g, uc, s, vc);
+            c_copy(c, uc, u);
+            c_copy(c, vc.t(), vt, true);  // vt = vc^H
+        }
     } else {
         // a^H = U' S V'^H  =>  a = V' S U'^H
-        CV<R> g = tmp_cm<R>(c, n, m), uc = tmp_cm<R>(c, n, m), vc = tmp_cm<R>(c, m, m);
-        c_copy(c, a.t(), g, true);
-        c_jacobi_svd_tall(c, g, uc, s, vc);
-        c_copy(c, vc, u);
-        c_copy(c, uc.t(), vt, true);
+        if (qr_first) {
+            CV<R> ah = tmp_cm<R>(c, n, m), q = tmp_cm<R>(c, n, m), rr = tmp_cm<R>(c, m, m), rp = tmp_cm<R>(c, m, m), ur = tmp_cm<R>(c, m, m), vc = tmp_cm<R>(c, m, m);
+            int64_t *ind = c->alloc<int64_t>((size_t)m);
+            c_copy(c, a.t(), ah, true);
+            c_pivoted_qr(c, ah, q, rr, ind, m);  // a^H P = q rr
+            c_colinv(c, rr, ind, rp);
+            c_jacobi_svd_tall(c, rp, ur, s, vc); // rr P^H = ur S vc^H  =>  a^H = (q ur) S vc^H  =>  a = vc S (q ur)^H
+            CV<R> qu = tmp_cm<R>(c, n, m);
+            c_gemm<R>(c, 0, 0, one<R>(), q, ur, zero<R>(), qu);
+            c_copy(c, vc, u);
+            c_copy(c, qu.t(), vt, true);
+        } else {
+            CV<R> g = tmp_cm<R>(c, n, m), uc = tmp_cm<R>(c, n, m), vc = tmp_cm<R>(c, m, m);
+            c_copy(c, a.t(), g, true);
+            c_jacobi_svd_tall(c, g, uc, s, vc);
+            c_copy(c, vc, u);
+            c_copy(c, uc.t(), vt, true);
+        }
     }
 }
 
