@@ -336,7 +336,8 @@ rc_status rc_sample_range_adaptive_f32(rc_context *ctx, rc_matrix a, double rel_
  * unless it has to; it cannot be recorded into a hipGraph (RC_INVALID_ARGUMENT while capturing).
  * The *_op_* entry points below run the same internal steps as their dense twins with the two products replaced by the callbacks:
  * a dense matrix behind callbacks that call rc_matmat / rc_conj_matmat reproduces the dense entry point bit for bit (f64; the f32
- * products pick their tiles by operand layout, so there the agreement is to rounding). */
+ * products pick their tiles by operand layout, so there the agreement is to rounding).  The complex scalar types have the same
+ * entry points (rc_*_op_c64 / _c32, declared with the complex instantiations below; rc_rsvd_id_op_* is real-only). */
 typedef struct rc_operator rc_operator;
 typedef int32_t (*rc_operator_product_fn)(void *user, rc_context *ctx, rc_matrix x, rc_matrix y); /* returns an rc_status */
 struct rc_operator {
@@ -490,6 +491,12 @@ rc_status rc_column_id_two_sided_c64(rc_context *ctx, rc_matrix c, rc_matrix c_o
 rc_status rc_row_id_two_sided_c64(rc_context *ctx, rc_matrix r, rc_matrix x, rc_matrix r_out, int64_t *col_ind);
 rc_status rc_max_col_norm_c64(rc_context *ctx, rc_matrix y, double *out);
 rc_status rc_sample_range_by_rank_c64(rc_context *ctx, rc_matrix a, int64_t k, int64_t p, rc_matrix omega, uint64_t seed, rc_matrix q);
+/* the operator-callback entry points (rc_operator, above) for c64: views are interleaved complex, strides in complex elements */
+rc_status rc_sample_range_by_rank_op_c64(rc_context *ctx, const rc_operator *op, int64_t k, int64_t p, rc_matrix omega, uint64_t seed, rc_matrix q);
+rc_status rc_sample_range_power_iteration_op_c64(rc_context *ctx, const rc_operator *op, int64_t k, int64_t p, int64_t it_count, rc_matrix omega, uint64_t seed, rc_matrix q);
+rc_status rc_sample_range_adaptive_op_c64(rc_context *ctx, const rc_operator *op, double rel_tol, int64_t sample_size, rc_matrix omegas, uint64_t seed, rc_matrix q_cap, int64_t *rank, int64_t *hist_rank, double *hist_res, int64_t hist_cap, int64_t *hist_len);
+rc_status rc_qr_from_range_estimate_op_c64(rc_context *ctx, rc_matrix range, const rc_operator *op, rc_matrix q, rc_matrix r, int64_t *ind);
+rc_status rc_svd_from_range_estimate_op_c64(rc_context *ctx, rc_matrix range, const rc_operator *op, rc_matrix u, double *s, rc_matrix vt);
 rc_status rc_sample_range_power_iteration_c64(rc_context *ctx, rc_matrix a, int64_t k, int64_t p, int64_t it_count, rc_matrix omega, uint64_t seed, rc_matrix q);
 rc_status rc_sample_range_adaptive_c64(rc_context *ctx, rc_matrix a, double rel_tol, int64_t sample_size, rc_matrix omegas, uint64_t seed, rc_matrix q_cap, int64_t *rank, int64_t *hist_rank, double *hist_res, int64_t hist_cap, int64_t *hist_len);
 rc_status rc_column_id_rank_c64(rc_context *ctx, rc_matrix a, int64_t k, rc_matrix c, rc_matrix z, int64_t *col_ind);
@@ -519,6 +526,11 @@ rc_status rc_column_id_two_sided_c32(rc_context *ctx, rc_matrix c, rc_matrix c_o
 rc_status rc_row_id_two_sided_c32(rc_context *ctx, rc_matrix r, rc_matrix x, rc_matrix r_out, int64_t *col_ind);
 rc_status rc_max_col_norm_c32(rc_context *ctx, rc_matrix y, float *out);
 rc_status rc_sample_range_by_rank_c32(rc_context *ctx, rc_matrix a, int64_t k, int64_t p, rc_matrix omega, uint64_t seed, rc_matrix q);
+rc_status rc_sample_range_by_rank_op_c32(rc_context *ctx, const rc_operator *op, int64_t k, int64_t p, rc_matrix omega, uint64_t seed, rc_matrix q);
+rc_status rc_sample_range_power_iteration_op_c32(rc_context *ctx, const rc_operator *op, int64_t k, int64_t p, int64_t it_count, rc_matrix omega, uint64_t seed, rc_matrix q);
+rc_status rc_sample_range_adaptive_op_c32(rc_context *ctx, const rc_operator *op, double rel_tol, int64_t sample_size, rc_matrix omegas, uint64_t seed, rc_matrix q_cap, int64_t *rank, int64_t *hist_rank, double *hist_res, int64_t hist_cap, int64_t *hist_len);
+rc_status rc_qr_from_range_estimate_op_c32(rc_context *ctx, rc_matrix range, const rc_operator *op, rc_matrix q, rc_matrix r, int64_t *ind);
+rc_status rc_svd_from_range_estimate_op_c32(rc_context *ctx, rc_matrix range, const rc_operator *op, rc_matrix u, float *s, rc_matrix vt);
 rc_status rc_sample_range_power_iteration_c32(rc_context *ctx, rc_matrix a, int64_t k, int64_t p, int64_t it_count, rc_matrix omega, uint64_t seed, rc_matrix q);
 rc_status rc_sample_range_adaptive_c32(rc_context *ctx, rc_matrix a, double rel_tol, int64_t sample_size, rc_matrix omegas, uint64_t seed, rc_matrix q_cap, int64_t *rank, int64_t *hist_rank, double *hist_res, int64_t hist_cap, int64_t *hist_len);
 rc_status rc_column_id_rank_c32(rc_context *ctx, rc_matrix a, int64_t k, rc_matrix c, rc_matrix z, int64_t *col_ind);

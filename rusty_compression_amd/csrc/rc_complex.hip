@@ -695,8 +695,49 @@ void c_max_col_norm_dev(rc_context *c, CV<R> y, R *out_dev) {
     max_sqrt<R>(c, ss, y.cols, out_dev);
 }
 // SampleRange::sample_range_by_rank (src/random_sampling.rs:103-118)
+// The operator the complex range finders sample (the real twin is OpView in rc_api.hip): a dense device matrix or the host's
+// callback table (rc_operator; the views handed over are interleaved-complex rc_matrix descriptors, strides in complex elements).
+// conj_matmat is A^H x (src/types.rs:128-132); the projection B = Q^H A is the conjugate transpose of the callback's A^H Q
+// (the reference: conj_matmat(..).t().map(conj), src/qr.rs:316-317), one conjugating copy.
 template <typename R>
-void c_sample_range_by_rank(rc_context *c, CV<R> a, int64_t k, int64_t p, CV<R> omega, uint64_t seed, CV<R> q) {
+struct COp {
+    int64_t rows = 0, cols = 0;
+    CV<R> dense{nullptr, 0, 0, 0, 0};
+    const rc_operator *cb = nullptr;
+    static COp of(CV<R> a) { COp o; o.rows = a.rows; o.cols = a.cols; o.dense = a; return o; }
+    static COp of(const rc_operator *op) {
+        RC_REQUIRE(op != nullptr && op->matmat != nullptr && op->rows >= 0 && op->cols >= 0, RC_INVALID_ARGUMENT, "rc_operator: null table / matmat or negative extent");
+        COp o; o.rows = op->rows; o.cols = op->cols; o.cb = op; return o;
+    }
+    static rc_matrix to_c(CV<R> m) { rc_matrix r; r.data = m.p; r.rows = m.rows; r.cols = m.cols; r.row_stride = m.rs; r.col_stride = m.cs; return r; }
+    void call(rc_context *c, rc_operator_product_fn fn, const char *what, CV<R> x, CV<R> y) const {
+        RC_REQUIRE(fn != nullptr, RC_INVALID_ARGUMENT, "rc_operator: this call needs the operator's %s", what);
+        RC_REQUIRE(!c->capturing, RC_INVALID_ARGUMENT, "rc_operator: callbacks cannot be recorded into a hipGraph");
+        const rc_status st = fn(cb->user, c, to_c(x), to_c(y));
+        if (st != RC_OK) fail(st, "operator callback %s (%lld x %lld -> %lld x %lld) returned status %d", what, (long long)x.rows, (long long)x.cols, (long long)y.rows, (long long)y.cols, (int)st);
+    }
+    void matmat(rc_context *c, CV<R> x, CV<R> y) const {
+        RC_REQUIRE(x.rows == cols && y.rows == rows && x.cols == y.cols, RC_INVALID_ARGUMENT, "matmat: shape mismatch");
+        if (cb) call(c, cb->matmat, "matmat", x, y);
+        else c_gemm(c, 0, 0, one<R>(), dense, x, zero<R>(), y);
+    }
+    void conj_matmat(rc_context *c, CV<R> x, CV<R> y) const {
+        RC_REQUIRE(x.rows == rows && y.rows == cols && x.cols == y.cols, RC_INVALID_ARGUMENT, "conj_matmat: shape mismatch");
+        if (cb) call(c, cb->conj_matmat, "conj_matmat", x, y);
+        else c_gemm(c, 2, 0, one<R>(), dense, x, zero<R>(), y);
+    }
+    // b (k x n) = range^H A
+    void project(rc_context *c, CV<R> range, CV<R> b) const {
+        if (!cb) { c_gemm(c, 2, 0, one<R>(), range, dense, zero<R>(), b); return; }
+        ArenaMark mark(c);
+        CV<R> t = tmp_cm<R>(c, cols, range.cols);
+        conj_matmat(c, range, t);
+        c_copy(c, t.t(), b, true);
+    }
+};
+
+template <typename R>
+void c_sample_range_by_rank(rc_context *c, const COp<R> &a, int64_t k, int64_t p, CV<R> omega, uint64_t seed, CV<R> q) {
     const int64_t m = a.rows, n = a.cols, l = k + p;
     RC_REQUIRE(k >= 0 && p >= 0, RC_INVALID_ARGUMENT, "sample_range_by_rank: negative k or p");
     const int64_t kk = std::min(k, std::min(m, l));
@@ -710,7 +751,7 @@ void c_sample_range_by_rank(rc_context *c, CV<R> a, int64_t k, int64_t p, CV<R> 
         RC_REQUIRE(omega.rows == n && omega.cols == l, RC_INVALID_ARGUMENT, "sample_range_by_rank: omega must be %lld x %lld", (long long)n, (long long)l);
     }
     CV<R> y = tmp_cm<R>(c, m, l);
-    c_gemm(c, 0, 0, one<R>(), a, omega, zero<R>(), y);
+    a.matmat(c, omega, y);
     int64_t *ind = c->alloc<int64_t>((size_t)l);
     c_pivoted_qr(c, y, q, CV<R>{nullptr, 0, 0, 0, 0}, ind, kk);
 }
@@ -724,7 +765,7 @@ CV<R> c_orth_full(rc_context *c, CV<R> w) {
 }
 // SampleRangePowerIteration (src/random_sampling.rs:131-160) with the reference's single surviving step
 template <typename R>
-void c_sample_range_power(rc_context *c, CV<R> a, int64_t k, int64_t p, int64_t it_count, CV<R> omega, uint64_t seed, CV<R> q) {
+void c_sample_range_power(rc_context *c, const COp<R> &a, int64_t k, int64_t p, int64_t it_count, CV<R> omega, uint64_t seed, CV<R> q) {
     if (it_count <= 0) { c_sample_range_by_rank(c, a, k, p, omega, seed, q); return; }
     const int64_t m = a.rows, n = a.cols, l = k + p;
     ArenaMark mark(c);
@@ -735,15 +776,15 @@ void c_sample_range_power(rc_context *c, CV<R> a, int64_t k, int64_t p, int64_t 
         RC_REQUIRE(omega.rows == n && omega.cols == l, RC_INVALID_ARGUMENT, "sample_range_power_iteration: omega must be %lld x %lld", (long long)n, (long long)l);
     }
     CV<R> y1 = tmp_cm<R>(c, m, l);
-    c_gemm(c, 0, 0, one<R>(), a, omega, zero<R>(), y1);
+    a.matmat(c, omega, y1);
     const int64_t steps = c->opt_power_fixed ? it_count : 1;
     for (int64_t it = 0; it < steps; ++it) {
         CV<R> q0 = c_orth_full(c, y1);
         CV<R> z = tmp_cm<R>(c, n, q0.cols);
-        c_gemm(c, 2, 0, one<R>(), a, q0, zero<R>(), z);  // conj_matmat
+        a.conj_matmat(c, q0, z);
         CV<R> wq = c_orth_full(c, z);
         y1 = tmp_cm<R>(c, m, wq.cols);
-        c_gemm(c, 0, 0, one<R>(), a, wq, zero<R>(), y1);
+        a.matmat(c, wq, y1);
     }
     const int64_t kk = std::min(k, std::min(m, y1.cols));
     RC_REQUIRE(q.rows == m && q.cols == kk, RC_INVALID_ARGUMENT, "sample_range_power_iteration: q must be %lld x %lld", (long long)m, (long long)kk);
@@ -752,7 +793,7 @@ void c_sample_range_power(rc_context *c, CV<R> a, int64_t k, int64_t p, int64_t 
 }
 // AdaptiveSampling::sample_range_adaptive (src/random_sampling.rs:223-274)
 template <typename R>
-void c_sample_range_adaptive(rc_context *c, CV<R> a, double rel_tol_d, int64_t s, CV<R> omegas, uint64_t seed, CV<R> qcap, int64_t *rank_out, int64_t *hist_rank,
+void c_sample_range_adaptive(rc_context *c, const COp<R> &a, double rel_tol_d, int64_t s, CV<R> omegas, uint64_t seed, CV<R> qcap, int64_t *rank_out, int64_t *hist_rank,
                              double *hist_res, int64_t hist_cap, int64_t *hist_len) {
     const int64_t m = a.rows, n = a.cols, cap = qcap.cols;
     RC_REQUIRE(s >= 1 && qcap.rows == m, RC_INVALID_ARGUMENT, "sample_range_adaptive: bad sample_size or q buffer");
@@ -775,7 +816,7 @@ void c_sample_range_adaptive(rc_context *c, CV<R> a, double rel_tol_d, int64_t s
         ++blocks_used;
     };
     next_omega();
-    c_gemm(c, 0, 0, one<R>(), a, omega, zero<R>(), y);
+    a.matmat(c, omega, y);
     R mc;
     c_max_col_norm_dev(c, y, scal);
     read_back_r(c, scal, &mc, 1);
@@ -792,13 +833,13 @@ void c_sample_range_adaptive(rc_context *c, CV<R> a, double rel_tol_d, int64_t s
         }
         CV<R> qnew = qacc.sub(0, m, r, sq);
         c_pivoted_qr(c, y, qnew, CV<R>{nullptr, 0, 0, 0, 0}, ind, sq);
-        c_gemm(c, 2, 0, one<R>(), qnew, a, zero<R>(), bacc.sub(r, sq, 0, n));  // b = [b ; (A^H Q_new)^H] = Q_new^H A
+        a.project(c, qnew, bacc.sub(r, sq, 0, n));  // b = [b ; (A^H Q_new)^H] = Q_new^H A
         r += sq;
         next_omega();
         {
             CV<R> qr_ = qacc.sub(0, m, 0, r), tt = t1.sub(0, r, 0, s);
             c_gemm(c, 0, 0, one<R>(), bacc.sub(0, r, 0, n), omega, zero<R>(), tt);
-            c_gemm(c, 0, 0, one<R>(), a, omega, zero<R>(), y);
+            a.matmat(c, omega, y);
             c_gemm(c, 0, 0, minus_one, qr_, tt, one<R>(), y);
         }
         c_max_col_norm_dev(c, y, scal);
@@ -823,8 +864,14 @@ rc_status guarded_c(rc_context *ctx, F &&f) {
     (void)hipGetDevice(&prev);
     if (prev != ctx->device) (void)hipSetDevice(ctx->device);
     rc_status st = RC_OK;
+    // (calls nest: an operator callback may use the library on the same context -- only the outermost call resets the arena)
+    struct Scope {
+        rc_context *c; size_t off = 0; bool outer;
+        explicit Scope(rc_context *x) : c(x), outer(x->call_depth++ == 0) { if (outer) c->reset_arena(); else off = c->arena_off; }
+        ~Scope() { --c->call_depth; if (!outer) c->arena_off = off; }
+    };
     try {
-        ctx->reset_arena();
+        Scope scope(ctx);
         f();
         hipError_t e = hipGetLastError();
         if (e != hipSuccess) fail(RC_RUNTIME_ERROR, "kernel launch failed: %s", hipGetErrorString(e));
@@ -886,7 +933,7 @@ void c_rsvd_id(rc_context *c, CV<R> a, int64_t k, int64_t p, CV<R> omega, uint64
     CV<R> range = view_of<R>(o.range_q);
     if (range.p == nullptr) range = tmp_cm<R>(c, m, k);
     RC_REQUIRE(range.rows == m && range.cols == k, RC_INVALID_ARGUMENT, "rsvd_id: range_q must be m x k");
-    c_sample_range_by_rank<R>(c, a, k, p, omega, seed, range);
+    c_sample_range_by_rank<R>(c, COp<R>::of(a), k, p, omega, seed, range);
     CV<R> b = tmp_cm<R>(c, k, n);
     c_gemm<R>(c, 2, 0, one<R>(), range, a, zero<R>(), b);
     const bool want_id = o.id_c.data || o.id_z.data || o.qr_q.data || o.qr_r.data || o.qr_ind;
@@ -1092,15 +1139,52 @@ extern "C" {
         });                                                                                                                               \
     }                                                                                                                                     \
     rc_status rc_sample_range_by_rank_##SUF(rc_context *ctx, rc_matrix a, int64_t k, int64_t p, rc_matrix omega, uint64_t seed, rc_matrix q) { \
-        return guarded_c(ctx, [&] { c_sample_range_by_rank<R>(ctx, view_of<R>(a), k, p, view_of<R>(omega), seed, view_of<R>(q)); });      \
+        return guarded_c(ctx, [&] { c_sample_range_by_rank<R>(ctx, COp<R>::of(view_of<R>(a)), k, p, view_of<R>(omega), seed, view_of<R>(q)); }); \
     }                                                                                                                                     \
     rc_status rc_sample_range_power_iteration_##SUF(rc_context *ctx, rc_matrix a, int64_t k, int64_t p, int64_t it, rc_matrix omega, uint64_t seed, rc_matrix q) { \
-        return guarded_c(ctx, [&] { c_sample_range_power<R>(ctx, view_of<R>(a), k, p, it, view_of<R>(omega), seed, view_of<R>(q)); });    \
+        return guarded_c(ctx, [&] { c_sample_range_power<R>(ctx, COp<R>::of(view_of<R>(a)), k, p, it, view_of<R>(omega), seed, view_of<R>(q)); }); \
     }                                                                                                                                     \
     rc_status rc_sample_range_adaptive_##SUF(rc_context *ctx, rc_matrix a, double rel_tol, int64_t s, rc_matrix omegas, uint64_t seed, rc_matrix q_cap, \
                                              int64_t *rank, int64_t *hist_rank, double *hist_res, int64_t hist_cap, int64_t *hist_len) {  \
         return guarded_c(ctx, [&] {                                                                                                       \
-            c_sample_range_adaptive<R>(ctx, view_of<R>(a), rel_tol, s, view_of<R>(omegas), seed, view_of<R>(q_cap), rank, hist_rank, hist_res, hist_cap, hist_len); \
+            c_sample_range_adaptive<R>(ctx, COp<R>::of(view_of<R>(a)), rel_tol, s, view_of<R>(omegas), seed, view_of<R>(q_cap), rank, hist_rank, hist_res, hist_cap, hist_len); \
+        });                                                                                                                               \
+    }                                                                                                                                     \
+    /* the range finders and compute_from_range_estimate over the host's operator callbacks (rc_operator) */                              \
+    rc_status rc_sample_range_by_rank_op_##SUF(rc_context *ctx, const rc_operator *op, int64_t k, int64_t p, rc_matrix omega, uint64_t seed, rc_matrix q) { \
+        return guarded_c(ctx, [&] { c_sample_range_by_rank<R>(ctx, COp<R>::of(op), k, p, view_of<R>(omega), seed, view_of<R>(q)); });     \
+    }                                                                                                                                     \
+    rc_status rc_sample_range_power_iteration_op_##SUF(rc_context *ctx, const rc_operator *op, int64_t k, int64_t p, int64_t it, rc_matrix omega, uint64_t seed, rc_matrix q) { \
+        return guarded_c(ctx, [&] { c_sample_range_power<R>(ctx, COp<R>::of(op), k, p, it, view_of<R>(omega), seed, view_of<R>(q)); });   \
+    }                                                                                                                                     \
+    rc_status rc_sample_range_adaptive_op_##SUF(rc_context *ctx, const rc_operator *op, double rel_tol, int64_t s, rc_matrix omegas, uint64_t seed, rc_matrix q_cap, \
+                                                int64_t *rank, int64_t *hist_rank, double *hist_res, int64_t hist_cap, int64_t *hist_len) { \
+        return guarded_c(ctx, [&] {                                                                                                       \
+            c_sample_range_adaptive<R>(ctx, COp<R>::of(op), rel_tol, s, view_of<R>(omegas), seed, view_of<R>(q_cap), rank, hist_rank, hist_res, hist_cap, hist_len); \
+        });                                                                                                                               \
+    }                                                                                                                                     \
+    rc_status rc_qr_from_range_estimate_op_##SUF(rc_context *ctx, rc_matrix range, const rc_operator *op, rc_matrix q, rc_matrix r, int64_t *ind) { \
+        return guarded_c(ctx, [&] {                                                                                                       \
+            const COp<R> A = COp<R>::of(op);                                                                                              \
+            CV<R> Rg = view_of<R>(range), Q = view_of<R>(q), Rr = view_of<R>(r);                                                          \
+            const int64_t rr = Rg.cols, n = A.cols, k = std::min(rr, n);                                                                  \
+            RC_REQUIRE(Rg.rows == A.rows && Q.rows == A.rows && Q.cols == k && Rr.rows == k && Rr.cols == n, RC_INVALID_ARGUMENT, "qr_from_range_estimate: shape mismatch"); \
+            CV<R> b = tmp_cm<R>(ctx, rr, n), qb = tmp_cm<R>(ctx, rr, k);                                                                  \
+            A.project(ctx, Rg, b);                                                                                                        \
+            c_pivoted_qr<R>(ctx, b, qb, Rr, ind, k);                                                                                      \
+            c_gemm<R>(ctx, 0, 0, one<R>(), Rg, qb, zero<R>(), Q);                                                                         \
+        });                                                                                                                               \
+    }                                                                                                                                     \
+    rc_status rc_svd_from_range_estimate_op_##SUF(rc_context *ctx, rc_matrix range, const rc_operator *op, rc_matrix u, R *s, rc_matrix vt) { \
+        return guarded_c(ctx, [&] {                                                                                                       \
+            const COp<R> A = COp<R>::of(op);                                                                                              \
+            CV<R> Rg = view_of<R>(range), U = view_of<R>(u), VT = view_of<R>(vt);                                                         \
+            const int64_t rr = Rg.cols, n = A.cols, r = std::min(rr, n);                                                                  \
+            RC_REQUIRE(Rg.rows == A.rows && U.rows == A.rows && U.cols == r && VT.rows == r && VT.cols == n, RC_INVALID_ARGUMENT, "svd_from_range_estimate: shape mismatch"); \
+            CV<R> b = tmp_cm<R>(ctx, rr, n), ub = tmp_cm<R>(ctx, rr, r);                                                                  \
+            A.project(ctx, Rg, b);                                                                                                        \
+            c_compute_svd<R>(ctx, b, ub, s, VT);                                                                                          \
+            c_gemm<R>(ctx, 0, 0, one<R>(), Rg, ub, zero<R>(), U);                                                                         \
         });                                                                                                                               \
     }                                                                                                                                     \
     rc_status rc_column_id_rank_##SUF(rc_context *ctx, rc_matrix a, int64_t k, rc_matrix c, rc_matrix z, int64_t *col_ind) {              \

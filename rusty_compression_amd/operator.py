@@ -36,7 +36,7 @@ class rc_operator(ctypes.Structure):
     ]
 
 
-_TYPESTR = {torch.float64: "<f8", torch.float32: "<f4"}
+_TYPESTR = {torch.float64: "<f8", torch.float32: "<f4", torch.complex128: "<c16", torch.complex64: "<c8"}
 
 
 class _DeviceView:
@@ -138,14 +138,14 @@ class LowRankOperator(Operator):
         return self.v.shape[0]
 
     def matmat(self, x):
-        from .types import dot
+        from .types import conj_matmat, dot
 
-        return dot(self.u, dot(self.v.t(), x))
+        return dot(self.u, conj_matmat(self.v, x))      # U (V^H x)
 
     def conj_matmat(self, x):
-        from .types import dot
+        from .types import conj_matmat, dot
 
-        return dot(self.v, dot(self.u.t(), x))
+        return dot(self.v, conj_matmat(self.u, x))      # V (U^H x)
 
 
 def is_operator(op) -> bool:

@@ -224,3 +224,53 @@ def test_get_stream_returns_the_context_stream():
     out = ctypes.c_void_p()
     assert _lib.lib().rc_get_stream(ctx._h, ctypes.byref(out)) == 0 and (out.value or 0) == s.cuda_stream
     ctx.close()
+
+
+@pytest.mark.parametrize("dtype", [np.complex128, np.complex64])
+def test_complex_operators_behind_callbacks(dtype):
+    """rc_*_op_c64 / _c32 (the reference instantiates its operator-generic range finders for c32 / c64 too: src/random_sampling.rs:123-126,
+    :165-168, :277-280).  A dense complex matrix behind callbacks against the dense entry points (to rounding: the projection
+    B = Q^H A is the conjugate transpose of the callback's A^H Q, another product than the dense path's), and a factored operator
+    U V^H never materialised against the oracle on the host product."""
+    real = np.float64 if dtype == np.complex128 else np.float32
+    tol = TOL[np.dtype(real)]
+    rng = np.random.default_rng(8)
+    m, n, r, k, p = 900, 640, 40, 20, 6
+    u = np.linalg.qr(rng.standard_normal((m, r)) + 1j * rng.standard_normal((m, r)))[0] * np.geomspace(1.0, 1e-6 if real == np.float64 else 1e-3, r)
+    v = np.linalg.qr(rng.standard_normal((n, r)) + 1j * rng.standard_normal((n, r)))[0]
+    u, v = u.astype(dtype), v.astype(dtype)
+    a_host = (u.astype(np.complex128) @ v.astype(np.complex128).conj().T).astype(dtype)
+    a = torch.from_numpy(a_host).cuda()
+    omega = (rng.standard_normal((n, k + p)) + 1j * rng.standard_normal((n, k + p))).astype(dtype)
+
+    dense_op, lr_op = DenseOperator(a), LowRankOperator(u, v)
+    q_d = rc.sample_range_by_rank(a, k, p, omega)
+    q_o = rc.sample_range_by_rank(dense_op, k, p, omega)
+    assert torch.equal(q_d, q_o)                      # the sketch is the same product on the same views
+    q_l = rc.sample_range_by_rank(lr_op, k, p, omega)
+    oq = o.sample_range_by_rank(a_host, k, p, lambda s: omega)
+    assert rel(npy(q_l) @ (npy(q_l).conj().T @ a_host), oq @ (oq.conj().T @ a_host)) <= 100 * tol["factor"]
+
+    s_d = rc.SVD.compute_from_range_estimate(q_d, a)
+    s_o = rc.SVD.compute_from_range_estimate(q_d, dense_op)
+    s_l = rc.SVD.compute_from_range_estimate(q_d, lr_op)
+    osvd = o.SVD.compute_from_range_estimate(npy(q_d), a_host)
+    for sv in (s_d, s_o, s_l):
+        assert np.abs(npy(sv.s) - osvd.s).max() / osvd.s[0] <= 10 * tol["sval"]
+        assert rel(npy(sv.to_mat()), osvd.to_mat()) <= 10 * tol["factor"]
+    r_o = rc.QR.compute_from_range_estimate(q_d, dense_op)
+    r_l = rc.QR.compute_from_range_estimate(q_d, lr_op)
+    oqr = o.QR.compute_from_range_estimate(npy(q_d), a_host)
+    for qr in (r_o, r_l):
+        assert np.array_equal(npy(qr.ind)[:6], oqr.ind[:6])
+        assert rel(npy(qr.to_mat()), oqr.to_mat()) <= 10 * tol["factor"]
+    qp = rc.sample_range_power_iteration(lr_op, k, p, 1, omega)
+    oqp = o.sample_range_power_iteration(a_host, k, p, 1, lambda s: omega)
+    assert rel(npy(qp) @ (npy(qp).conj().T @ a_host), oqp @ (oqp.conj().T @ a_host)) <= 100 * tol["factor"]
+    s_ = 8
+    omegas = (rng.standard_normal((n, s_ * 12)) + 1j * rng.standard_normal((n, s_ * 12))).astype(dtype)
+    rel_tol = 1e-4 if real == np.float64 else 1e-2
+    qa, hist = rc.sample_range_adaptive(lr_op, rel_tol, s_, omegas)
+    blocks = iter(range(12))
+    oqa, ohist = o.sample_range_adaptive(a_host, rel_tol, s_, lambda shape: omegas[:, (i := next(blocks)) * s_:(i + 1) * s_])
+    assert [x for x, _ in hist] == [x for x, _ in ohist]
