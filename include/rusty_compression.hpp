@@ -541,6 +541,8 @@ template <typename T> struct ApiOp;
     };
 RC_API_OP(double, f64)
 RC_API_OP(float, f32)
+RC_API_OP(c64, c64)
+RC_API_OP(c32, c32)
 #undef RC_API_OP
 
 namespace detail {
