@@ -398,6 +398,254 @@ __global__ __launch_bounds__(LPP == 16 ? 1024 : 512) void k_jacobi_lds(Mat<T> g,
 }
 
 // ---------------------------------------------------------------------------
+// Two-column BLOCK schedule of the fused one-sided Jacobi (round 3; n = 128 = 16 lanes x 8 rows, the core of the headline
+// pipeline).  k_jacobi_lds visits the 8128 column pairs of a sweep in 127 rounds of 64 disjoint pairs: every rotation costs two
+// column loads, two column stores and a share of a workgroup barrier.  Here the columns form 64 blocks of two neighbours; a sweep
+// is ONE round of the 64 intra-block pairs plus a 63-round tournament of the blocks (circle method), and a group of 16 lanes that
+// meets block pair {X, Y} loads its FOUR columns once, rotates the four cross pairs in two phases of two INDEPENDENT rotations --
+// (x0, y0) & (x1, y1), then (x0, y1) & (x1, y0) -- and stores them once: half the LDS traffic and half the barriers per
+// rotation (64 instead of 127 per sweep), and two independent dependent chains per lane to fill the issue slots.  Every pair of
+// columns still meets exactly once per sweep (a cyclic-by-blocks ordering); the rotation, its threshold, the two-part
+// convergence test, the singular-value sort and the record protocol (J1 - J6 above; records indexed (sweep, 64 intra | round,
+// slot, 0..3)) are k_jacobi_lds's.  512 threads = 32 groups = one per block pair.  The consumer workgroup mirrors the schedule on V.
+// ---------------------------------------------------------------------------
+template <typename T>
+__device__ __forceinline__ void jb2_rotate(T (&a)[8], T (&b)[8], T tol, T tol2, Rot<T> &rot, int ll, int *sh_rot_p) {
+    T app = 0, aqq = 0, apq = 0;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { app = fma(a[e], a[e], app); aqq = fma(b[e], b[e], aqq); apq = fma(a[e], b[e], apq); }
+    app = group_sum_dpp<16>(app);
+    aqq = group_sum_dpp<16>(aqq);
+    apq = group_sum_dpp<16>(apq);
+    rot.c = (T)1;
+    rot.s = (T)0;
+    if (apq * apq > tol2 * app * aqq) {  // uniform over the 16 lanes
+        jacobi_rotation(app, aqq, apq, rot.c, rot.s);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const T x = a[e], y = b[e];
+            a[e] = rot.c * x - rot.s * y;
+            b[e] = rot.s * x + rot.c * y;
+        }
+        if (ll == 0 && (apq * apq > tol * (T)0.0625 * app * aqq || rot.s * rot.s > (T)16 * tol)) *sh_rot_p = 2;  // another sweep is needed (k_jacobi_lds)
+    }
+}
+template <typename T>
+__device__ __forceinline__ void jb2_apply(T (&a)[8], T (&b)[8], Rot<T> rot) {
+    if (rot.s != (T)0) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const T x = a[e], y = b[e];
+            a[e] = rot.c * x - rot.s * y;
+            b[e] = rot.s * x + rot.c * y;
+        }
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(512) void k_jacobi_b2(Mat<T> g, Rot<T> *log, int *sweeps_out, Mat<T> uc, T *s, int *order_out, int max_sweeps, unsigned *vsync,
+                                                    unsigned long long *chk, unsigned *epoch_p, Mat<T> vc, int *health, int ld) {
+    constexpr int n = 128, NB = 64, NR = NB - 1, NSLOT = NB / 2, LPP = 16, NE = 8;
+    constexpr int REC = NB + NR * NSLOT * 4;  // records per sweep = 8128 = (n - 1) * n / 2: the log of k_jacobi_lds has the same size
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    T *G = reinterpret_cast<T *>(smem_raw);
+    T *sig = G + (size_t)ld * n;
+    int *order = reinterpret_cast<int *>(sig + n);
+    __shared__ int sh_rot_b2;
+    const int tid = threadIdx.x, nthr = 512;
+    const int ll = tid % LPP, grp = tid / LPP, ngrp = nthr / LPP;  // 32 groups
+    // The two groups of a 32-lane half would both read an even column, then both an odd one: same offset in the bank row (the pitch is
+    // 16 mod 32 elements), a two-way conflict on every access.  Odd groups take the columns of a block in the other order, so one
+    // instruction reads an even and an odd column per half: conflict-free.  The pairs of a phase are the same sets either way --
+    // (x0, y0) & (x1, y1), then (x0, y1) & (x1, y0) -- only their order inside a phase differs, and the consumer uses the same rule.
+    const int sw = grp & 1;
+    const unsigned epoch = __hip_atomic_load(epoch_p, __ATOMIC_RELAXED, RC_AGENT) & 0xffffffu;
+    const unsigned long long key = epoch_key(epoch);
+    // the block pair of this group in tournament round rr: slot 0 pairs block NB - 1 with rr, slot i pairs (rr + i) with (rr - i) mod NR
+    auto blocks_of = [&](int pr, int qr, int &X, int &Y) {
+        X = grp == 0 ? NB - 1 : pr;
+        Y = grp == 0 ? pr : qr;
+        if (X > Y) { const int t = X; X = Y; Y = t; }  // X < Y: every cross pair (x_i, y_j) has x_i < y_j, the (p < q) convention of the rotation
+    };
+    if (blockIdx.x == 1) {
+        // ---- consumer: V = product of the rotations, the producer's schedule ----
+        constexpr int kSpin = 1 << 24;
+        T *V = G;
+        for (int e = tid; e < n * n; e += nthr) {
+            const int i = e % n, j = e / n;
+            V[j * ld + i] = (i == j) ? (T)1 : (T)0;
+        }
+        __syncthreads();
+        bool lost = false;
+        auto fetch = [&](size_t rec) -> Rot<T> {
+            Rot<T> rot{(T)1, (T)0};
+            bool ok = false;
+            for (int it = 0; it < kSpin && !(ok = rot_fetch(log + rec, chk + rec, rot, key)); ++it) __builtin_amdgcn_s_sleep(2);
+            if (!ok) { lost = true; rot.c = (T)1; rot.s = (T)0; }
+            return rot;
+        };
+        for (int sweep = 0;; ++sweep) {
+            if (tid == 0) {  // has the producer started this sweep, or did it finish before it?
+                int fin = 2;
+                for (int it = 0; it < kSpin; ++it) {
+                    const unsigned d = tagged_get(vsync, epoch);
+                    if (d != 0u && (int)d <= sweep) { fin = 1; break; }
+                    Rot<T> r0;
+                    if (sweep < max_sweeps && rot_fetch(log + (size_t)sweep * REC, chk + (size_t)sweep * REC, r0, key)) { fin = 0; break; }
+                    __builtin_amdgcn_s_sleep(8);
+                }
+                sh_rot_b2 = fin;
+            }
+            __syncthreads();
+            const int fin = sh_rot_b2;
+            __syncthreads();
+            if (fin) { lost = lost || fin == 2; break; }
+            const size_t base = (size_t)sweep * REC;
+            for (int h = 0; h < 2; ++h) {  // intra-block pairs
+                const int b = grp + ngrp * h;
+                const Rot<T> rot = fetch(base + b);
+                if (rot.s != (T)0) {
+                    T *vp = V + (2 * b) * ld, *vq = V + (2 * b + 1) * ld;
+                    T a[NE], c2[NE];
+#pragma unroll
+                    for (int e = 0; e < NE; ++e) { a[e] = vp[ll + LPP * e]; c2[e] = vq[ll + LPP * e]; }
+                    jb2_apply(a, c2, rot);
+#pragma unroll
+                    for (int e = 0; e < NE; ++e) { vp[ll + LPP * e] = a[e]; vq[ll + LPP * e] = c2[e]; }
+                }
+            }
+            lds_barrier();
+            int pr = grp % NR, qr = (NR - grp % NR) % NR;
+            for (int rr = 0; rr < NR; ++rr) {
+                int X, Y;
+                blocks_of(pr, qr, X, Y);
+                pr = pr + 1 == NR ? 0 : pr + 1;
+                qr = qr + 1 == NR ? 0 : qr + 1;
+                const size_t rec = base + NB + ((size_t)rr * NSLOT + grp) * 4;
+                const Rot<T> r0 = fetch(rec), r1 = fetch(rec + 1), r2 = fetch(rec + 2), r3 = fetch(rec + 3);
+                if (r0.s != (T)0 || r1.s != (T)0 || r2.s != (T)0 || r3.s != (T)0) {
+                    T *v0 = V + (2 * X + sw) * ld, *v1 = V + (2 * X + 1 - sw) * ld, *v2 = V + (2 * Y + sw) * ld, *v3 = V + (2 * Y + 1 - sw) * ld;
+                    T c0[NE], c1[NE], c2[NE], c3[NE];
+#pragma unroll
+                    for (int e = 0; e < NE; ++e) { const int i = ll + LPP * e; c0[e] = v0[i]; c1[e] = v1[i]; c2[e] = v2[i]; c3[e] = v3[i]; }
+                    jb2_apply(c0, c2, r0);
+                    jb2_apply(c1, c3, r1);
+                    jb2_apply(c0, c3, r2);
+                    jb2_apply(c1, c2, r3);
+#pragma unroll
+                    for (int e = 0; e < NE; ++e) { const int i = ll + LPP * e; v0[i] = c0[e]; v1[i] = c1[e]; v2[i] = c2[e]; v3[i] = c3[e]; }
+                }
+                lds_barrier();
+            }
+        }
+        // columns go out in the sorted order the producer publishes at its very end
+        for (int j = grp; j < n; j += ngrp) {
+            unsigned enc = 0;
+            for (int it = 0; it < kSpin && (enc = tagged_get(vsync + 1 + j, epoch)) == 0u; ++it) __builtin_amdgcn_s_sleep(8);
+            if (enc == 0u) { lost = true; continue; }
+            const int dst = (int)enc - 1;
+            for (int i = ll; i < n; i += LPP) vc.at(i, dst) = V[j * ld + i];
+        }
+        if (lost && ll == 0) atomicOr(health, 8);  // the producer never showed up within the spin bound: V is incomplete
+        __syncthreads();
+        if (tid == 0) __hip_atomic_fetch_add(epoch_p, 1u, __ATOMIC_RELAXED, RC_AGENT);  // the next launch uses a new key
+        return;
+    }
+    // ---- producer ----
+    const T tol = sqrt((T)n) * JEps<T>::eps();
+    const T tol2 = tol * tol;
+    for (int e = tid; e < n * n; e += nthr) {
+        const int i = e % n, j = e / n;
+        G[j * ld + i] = g.p[(int64_t)j * g.cs + i];
+    }
+    __syncthreads();
+    int sweep = 0;
+    bool converged = false;
+    for (; sweep < max_sweeps; ++sweep) {
+        if (tid == 0) sh_rot_b2 = 0;
+        __syncthreads();
+        const size_t base = (size_t)sweep * REC;
+        for (int h = 0; h < 2; ++h) {  // the 64 intra-block pairs (2 b, 2 b + 1)
+            const int b = grp + ngrp * h;
+            T *gp = G + (2 * b) * ld, *gq = G + (2 * b + 1) * ld;
+            T a[NE], c2[NE];
+#pragma unroll
+            for (int e = 0; e < NE; ++e) { a[e] = gp[ll + LPP * e]; c2[e] = gq[ll + LPP * e]; }
+            Rot<T> rot;
+            jb2_rotate(a, c2, tol, tol2, rot, ll, &sh_rot_b2);
+            if (rot.s != (T)0) {
+#pragma unroll
+                for (int e = 0; e < NE; ++e) { gp[ll + LPP * e] = a[e]; gq[ll + LPP * e] = c2[e]; }
+            }
+            if (ll == 0) rot_publish(log + base + b, chk + base + b, rot, key);
+        }
+        lds_barrier();
+        int pr = grp % NR, qr = (NR - grp % NR) % NR;
+        for (int rr = 0; rr < NR; ++rr) {
+            int X, Y;
+            blocks_of(pr, qr, X, Y);
+            pr = pr + 1 == NR ? 0 : pr + 1;
+            qr = qr + 1 == NR ? 0 : qr + 1;
+            T *g0 = G + (2 * X + sw) * ld, *g1 = G + (2 * X + 1 - sw) * ld, *g2 = G + (2 * Y + sw) * ld, *g3 = G + (2 * Y + 1 - sw) * ld;
+            T c0[NE], c1[NE], c2[NE], c3[NE];
+#pragma unroll
+            for (int e = 0; e < NE; ++e) { const int i = ll + LPP * e; c0[e] = g0[i]; c1[e] = g1[i]; c2[e] = g2[i]; c3[e] = g3[i]; }
+            Rot<T> r0, r1, r2, r3;
+            jb2_rotate(c0, c2, tol, tol2, r0, ll, &sh_rot_b2);   // phase 1: (x0, y0) and (x1, y1) are independent
+            jb2_rotate(c1, c3, tol, tol2, r1, ll, &sh_rot_b2);
+            jb2_rotate(c0, c3, tol, tol2, r2, ll, &sh_rot_b2);   // phase 2: (x0, y1) and (x1, y0)
+            jb2_rotate(c1, c2, tol, tol2, r3, ll, &sh_rot_b2);
+            if (r0.s != (T)0 || r1.s != (T)0 || r2.s != (T)0 || r3.s != (T)0) {
+#pragma unroll
+                for (int e = 0; e < NE; ++e) { const int i = ll + LPP * e; g0[i] = c0[e]; g1[i] = c1[e]; g2[i] = c2[e]; g3[i] = c3[e]; }
+            }
+            if (ll == 0) {
+                const size_t rec = base + NB + ((size_t)rr * NSLOT + grp) * 4;
+                rot_publish(log + rec, chk + rec, r0, key);
+                rot_publish(log + rec + 1, chk + rec + 1, r1, key);
+                rot_publish(log + rec + 2, chk + rec + 2, r2, key);
+                rot_publish(log + rec + 3, chk + rec + 3, r3, key);
+            }
+            lds_barrier();  // block pairs of one round are disjoint; the next round re-pairs the blocks
+        }
+        const int rotated = sh_rot_b2;
+        __syncthreads();
+        if (rotated < 2) { ++sweep; converged = true; break; }
+    }
+    if (tid == 0 && !converged && health) atomicOr(health, 16);  // sweep budget exhausted with rotations above the thresholds
+    if (tid == 0) {
+        *sweeps_out = sweep;
+        tagged_put(vsync, epoch, (unsigned)sweep);
+    }
+    // singular values = column norms; stable descending rank sort (gesdd order) -- as k_jacobi_lds
+    for (int j = grp; j < n; j += ngrp) {
+        const T *gj = G + j * ld;
+        T acc = 0;
+        for (int i = ll; i < n; i += LPP) acc += gj[i] * gj[i];
+        acc = group_sum_dpp<LPP>(acc);
+        if (ll == 0) sig[j] = sqrt(acc);
+    }
+    __syncthreads();
+    for (int i = tid; i < n; i += nthr) {
+        int rank = 0;
+        const T si = sig[i];
+        for (int j = 0; j < n; ++j) rank += (sig[j] > si || (sig[j] == si && j < i)) ? 1 : 0;
+        order[i] = rank;
+        order_out[i] = rank;
+        tagged_put(vsync + 1 + i, epoch, (unsigned)(rank + 1));
+        s[rank] = si;
+    }
+    __syncthreads();
+    for (int j = grp; j < n; j += ngrp) {
+        const int dst = order[j];
+        const T sj = sig[j];
+        const T inv = sj > (T)0 ? (T)1 / sj : (T)0;
+        const T *gj = G + j * ld;
+        for (int i = ll; i < n; i += LPP) uc.at(i, dst) = gj[i] * inv;
+    }
+}
+
+// ---------------------------------------------------------------------------
 // V = J_1 J_2 ... applied to I, row by row: one wave per row of V.
 // ---------------------------------------------------------------------------
 template <typename T, int RPW>
@@ -634,6 +882,20 @@ static void launch_lds_impl(rc_context *c, Mat<T> g, Mat<T> uc, T *s, Mat<T> vc,
         // contexts' first calls).  The epoch itself now starts at a per-context pseudo-random value (rc_context::epoch_word).
         static const int no_clear = [] { const char *e = getenv("RC_DEBUG_JACOBI_NO_CLEAR"); return e ? atoi(e) : 0; }();  // (diagnostic: the round-2 behaviour)
         if (!no_clear) hipLaunchKernelGGL(k_clear_words, dim3(1), dim3(256), 0, c->stream, vsync, n + 1);
+        // two-column block schedule (k_jacobi_b2) for the 128-column core: opt-in (RC_JACOBI_BLOCK2=1).  Measured in round 3: the same
+        // 9 sweeps, 1.80 ms against 1.77 ms for the pair-per-round schedule, headline unchanged -- the kernel is bound by the DEPENDENT
+        // chain of a rotation (dot products -> DPP reduction -> rsq / rcp + Newton -> update -> LDS), not by LDS traffic or barriers: a
+        // block round has two dependent phases, so half the rounds carry the same chain length (SVD)
+        static const int block2 = [] { const char *e = getenv("RC_JACOBI_BLOCK2"); return e ? atoi(e) : 0; }();
+        if (block2 && FULL && !CN && LPP == 16 && NE == 8 && n == 128) {
+            auto kb = k_jacobi_b2<T>;
+            static bool attr_b2[64] = {};
+            if (!attr_b2[c->device & 63]) {
+                RC_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kb), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 2048));
+                attr_b2[c->device & 63] = true;
+            }
+            hipLaunchKernelGGL(kb, dim3(2), dim3(512), lds, c->stream, g, log, sweeps, uc, s, order, max_sweeps, vsync, chk, c->epoch_word(), vc, c->health_word(), ld);
+        } else
         hipLaunchKernelGGL(kern, dim3(2), dim3(threads), lds, c->stream, g, log, sweeps, uc, s, order, max_sweeps, 1, vsync, chk, c->epoch_word(), vc, c->health_word(), ld);
     } else {
         hipLaunchKernelGGL(kern, dim3(1), dim3(threads), lds, c->stream, g, log, sweeps, uc, s, order, max_sweeps, 0, (unsigned *)nullptr, (unsigned long long *)nullptr,

@@ -1567,6 +1567,44 @@ def test_captured_pivoted_qr_of_a_blocked_eligible_shape_agrees_with_the_eager_o
     assert rel(gr[:ns, :ns], er[:ns, :ns]) <= 10 * tol and rel(gq[:, :ns], eq[:, :ns]) <= 100 * tol
 
 
+def test_two_column_block_schedule_of_the_fused_jacobi_gives_the_same_svd():
+    """k_jacobi_b2 (opt-in, RC_JACOBI_BLOCK2=1): the 128-column core's sweeps as one round of intra-block pairs + a 63-round tournament
+    of two-column blocks, four cross pairs per block pair in registers.  Another cyclic ordering of the same rotations: singular values
+    to 1e-13 of the default schedule's, U / V orthonormal, reconstruction to 1e-13, the right vectors complete (health word clean)."""
+    import os
+    import subprocess
+    import sys
+
+    snippet = r"""
+import numpy as np, torch, sys
+import rusty_compression_amd as rc
+from rusty_compression_amd import _lib
+rng = np.random.default_rng(12)
+for trial in range(3):
+    a = rng.standard_normal((128, 128)) * np.geomspace(1.0, 10.0 ** -(4 * trial), 128)
+    u, s, vt = rc.compute_svd(a)
+    u, s, vt = (t.cpu().numpy() for t in (u, s, vt))
+    print("SV " + " ".join("%.17e" % x for x in s))
+    print("ERR %.3e %.3e %.3e" % (np.abs(u.T @ u - np.eye(128)).max(), np.abs(vt @ vt.T - np.eye(128)).max(), np.linalg.norm((u * s) @ vt - a) / np.linalg.norm(a)))
+print("HEALTH", _lib.default_context().get_health())
+"""
+
+    def run(flag):
+        res = subprocess.run([sys.executable, "-c", snippet], env=dict(os.environ, RC_JACOBI_BLOCK2=flag), capture_output=True, text=True, timeout=300,
+                             cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+        assert res.returncode == 0, res.stdout[-1000:] + res.stderr[-1500:]
+        sv = [np.array([float(x) for x in ln.split()[1:]]) for ln in res.stdout.splitlines() if ln.startswith("SV ")]
+        err = [[float(x) for x in ln.split()[1:]] for ln in res.stdout.splitlines() if ln.startswith("ERR ")]
+        assert "HEALTH 0" in res.stdout
+        return sv, err
+
+    (sv1, err1), (sv0, err0) = run("1"), run("0")
+    assert len(sv1) == 3
+    for a, b, e in zip(sv1, sv0, err1):
+        assert np.abs(a - b).max() <= 1e-13 * b[0]
+        assert e[0] <= 1e-12 and e[1] <= 1e-12 and e[2] <= 1e-13
+
+
 def test_graph_replay_matches_eager_and_survives_workspace_growth():
     """hipGraph capture of the fused pipeline (rc_graph_*): the replay reproduces the eager result bit
     for bit, and an eager call that outgrows the workspace afterwards must not invalidate the graph
