@@ -48,6 +48,7 @@ static __host__ __device__ inline int64_t cdivb(int64_t a, int64_t b) { return (
 
 constexpr int kNB = 32;
 
+constexpr int kQrbVtaMaxSplits = 16;  // row chunks of the streaming Y = V^T A (k_qrb_vta): partial slabs summed by k_qrb_finish
 template <typename T> struct NumB;
 template <> struct NumB<double> {
     typedef unsigned long long key_t;
@@ -598,7 +599,7 @@ __global__ __launch_bounds__(256) void k_qrb_build_vp_pos(Mat<T> w, int j0, cons
 // ---------------------------------------------------------------------------
 template <typename T>
 __global__ __launch_bounds__(256) void k_qrb_finish(Mat<T> w, int j0, int kb, const int *pos, const unsigned char *is_cand, T *vn1, const T *vn2, T *Fm,
-                                                    const T *Y, int64_t ldy, const T *Tm, Mat<T> vp, int *flag, int coop) {
+                                                    const T *Y, int64_t ldy, const T *Tm, Mat<T> vp, int *flag, int coop, int nsplit, int64_t sstride) {
     __shared__ T Tl[kNB * kNB], Vl[kNB * kNB];
     for (int e = threadIdx.x; e < kNB * kNB; e += 256) {
         const int r = e % kNB, q = e / kNB;  // element (r, q)
@@ -620,7 +621,13 @@ __global__ __launch_bounds__(256) void k_qrb_finish(Mat<T> w, int j0, int kb, co
     {
         T y[kNB];
 #pragma unroll
-        for (int s = 0; s < kNB; ++s) y[s] = s < kb ? Y[(int64_t)s * ldy + c] : (T)0;
+        for (int s = 0; s < kNB; ++s) {
+            // Y arrives as nsplit partial slabs over the rows (k_qrb_vta): summed here in slab order (deterministic), no reduction launch
+            T acc = 0;
+            if (s < kb)
+                for (int sp = 0; sp < nsplit; ++sp) acc += Y[(int64_t)sp * sstride + (int64_t)s * ldy + c];
+            y[s] = acc;
+        }
 #pragma unroll
         for (int t = 0; t < kNB; ++t) {
             T acc = 0;
@@ -658,6 +665,131 @@ __global__ __launch_bounds__(256) void k_qrb_finish(Mat<T> w, int j0, int kb, co
     }
     vn1[c] = vn;
     if (lost) flag[c] = 1;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Y = V^T A for the panel end (f32; round 3): 32 x n from ONE read pass over the trailing matrix, HBM bound (32 flops per element of
+// A).  The generic MFMA GEMM reached 1.9 TB/s here (8 KB per workgroup and K tile in flight through LDS, then a split-K reduction
+// launch).  This kernel has no LDS and no barrier: a wave owns 64 columns x one chunk of rows and streams them with one 16-byte load
+// per lane and column block -- A is column-major, so a lane reads 4 consecutive rows of its column, the four 16-lane groups of a wave
+// 16 consecutive rows = one 64-byte sector per column -- and V the same way from L2 (32 x rows, re-read by every wave: 32 MB in all).
+// v_mfma_f32_16x16x4f32 with the operand layout validated in kernels_gemm.hip (A: row = lane % 16, k = lane / 16; B: k = lane / 16,
+// col = lane % 16; D[r]: row = 4 (lane / 16) + r, col = lane % 16): component t of the lanes' float4s is the MFMA's k-slot, so four
+// MFMAs consume the 16 rows of a step.  The row chunks' partial results go to `nsplit` slabs that k_qrb_finish sums in order.
+// Requires 16-byte aligned columns (j0 % 4 == 0, leading dimensions % 4 == 0): the host checks and otherwise takes the GEMM.
+// ---------------------------------------------------------------------------------------------------------------------
+typedef float vta_f4 __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(256) void k_qrb_vta(const float *v, int64_t ldv, const float *a, int64_t lda, int rows, int n, int kb, float *ypart, int64_t ldy,
+                                                 int64_t sstride, int rows_per_split) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int cl = lane & 15, g = lane >> 4;
+    const int c0 = (blockIdx.x * 4 + wave) * 64;
+    if (c0 >= n) return;  // whole wave (no barriers in this kernel)
+    const int split = blockIdx.y;
+    const int r0 = split * rows_per_split, r1 = min(rows, r0 + rows_per_split);
+    vta_f4 acc[2][4];
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[b][j] = vta_f4{0.f, 0.f, 0.f, 0.f};
+    const float *ap[4], *vp[2];
+    bool aok[4], vok[2];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int c = c0 + 16 * j + cl;
+        aok[j] = c < n;
+        ap[j] = a + (int64_t)(aok[j] ? c : 0) * lda + 4 * g;
+    }
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+        const int k = 16 * b + cl;
+        vok[b] = k < kb;
+        vp[b] = v + (int64_t)(vok[b] ? k : 0) * ldv + 4 * g;
+    }
+    auto load = [&](int i0, vta_f4 (&fa)[4], vta_f4 (&fv)[2]) {
+        if (i0 + 16 <= r1) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) fa[j] = aok[j] ? *reinterpret_cast<const vta_f4 *>(ap[j] + i0) : vta_f4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int b = 0; b < 2; ++b) fv[b] = vok[b] ? *reinterpret_cast<const vta_f4 *>(vp[b] + i0) : vta_f4{0.f, 0.f, 0.f, 0.f};
+        } else {  // the last, partial step of the matrix: element-wise with bounds
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int t = 0; t < 4; ++t) fa[j][t] = (aok[j] && i0 + 4 * g + t < r1) ? ap[j][i0 + t] : 0.f;
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+                for (int t = 0; t < 4; ++t) fv[b][t] = (vok[b] && i0 + 4 * g + t < r1) ? vp[b][i0 + t] : 0.f;
+        }
+    };
+    auto compute = [&](const vta_f4 (&fa)[4], const vta_f4 (&fv)[2]) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[b][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(fv[b][t], fa[j][t], acc[b][j], 0, 0, 0);
+    };
+    // three fragment sets in rotation: two steps of loads (12 x 16 bytes per lane) are in flight while one is consumed
+    vta_f4 fa0[4], fv0[2], fa1[4], fv1[2], fa2[4], fv2[2];
+    int i = r0;
+    if (i < r1) load(i, fa0, fv0);
+    if (i + 16 < r1) load(i + 16, fa1, fv1);
+    for (; i < r1; i += 48) {
+        if (i + 32 < r1) load(i + 32, fa2, fv2);
+        compute(fa0, fv0);
+        if (i + 16 >= r1) break;
+        if (i + 48 < r1) load(i + 48, fa0, fv0);
+        compute(fa1, fv1);
+        if (i + 32 >= r1) break;
+        if (i + 64 < r1) load(i + 64, fa1, fv1);
+        compute(fa2, fv2);
+    }
+    float *yp = ypart + (int64_t)split * sstride;
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int c = c0 + 16 * j + cl;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int k = 16 * b + 4 * g + r;
+                if (k < kb && c < n) yp[(int64_t)k * ldy + c] = acc[b][j][r];
+            }
+        }
+}
+// y[k][c] = sum over the slabs, in slab order (deterministic); slab 0 receives the sum.  (Folding this sum into k_qrb_finish was
+// measured: its 16 workgroups then issue 512 loads per thread and the panel end got 0.2 ms SLOWER.)
+__global__ __launch_bounds__(256) void k_qrb_ysum(float *ypart, int64_t ldy, int64_t sstride, int kb, int n, int nsplit) {
+    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (e >= (int64_t)kb * n) return;
+    const int k = (int)(e / n), c = (int)(e % n);
+    float *p = ypart + (int64_t)k * ldy + c;
+    float acc = 0.f;
+    for (int sp = 0; sp < nsplit; ++sp) acc += p[(int64_t)sp * sstride];
+    p[0] = acc;
+}
+template <typename T>
+static bool qrb_vta_launch(rc_context *, Mat<T>, Mat<T>, int, T *, int64_t, int64_t, int *) { return false; }
+// returns true and sets *nsplit when the streaming kernel ran (ypart: nsplit slabs of kNB x ldy); false: take the GEMM
+template <>
+bool qrb_vta_launch<float>(rc_context *c, Mat<float> vpp, Mat<float> wsub, int kb, float *ypart, int64_t ldy, int64_t sstride, int *nsplit) {
+    static const int on = [] { const char *e = getenv("RC_QRCP_VTA"); return e ? atoi(e) : 1; }();
+    const int64_t rows = wsub.rows, n = wsub.cols;
+    if (!on || wsub.rs != 1 || vpp.rs != 1 || rows < 256 || n < 64 || kb > kNB) return false;
+    if ((wsub.cs % 4) || (vpp.cs % 4) || (reinterpret_cast<uintptr_t>(wsub.p) % 16) || (reinterpret_cast<uintptr_t>(vpp.p) % 16)) return false;
+    // row chunks so that ~1024 waves exist (4 per CU): a chunk is a whole number of 16-row steps
+    const int64_t col_wgs = cdivb(n, 256);
+    int splits = (int)std::max<int64_t>(1, std::min<int64_t>(kQrbVtaMaxSplits, 256 / std::max<int64_t>(col_wgs, 1)));
+    int64_t rps = cdivb(cdivb(rows, splits), 16) * 16;
+    splits = (int)cdivb(rows, rps);
+    ProfScope ps(c, "kernel:k_qrb_vta rows=%lld n=%lld kb=%d splits=%d", (long long)rows, (long long)n, kb, splits);
+    hipLaunchKernelGGL(k_qrb_vta, dim3((unsigned)col_wgs, (unsigned)splits), dim3(256), 0, c->stream, vpp.p, vpp.cs, wsub.p, wsub.cs, (int)rows, (int)n, kb, ypart, ldy, sstride,
+                       (int)rps);
+    if (splits > 1) hipLaunchKernelGGL(k_qrb_ysum, dim3((unsigned)cdivb((int64_t)kb * n, 256)), dim3(256), 0, c->stream, ypart, ldy, sstride, kb, (int)n, splits);
+    *nsplit = 1;  // slab 0 holds Y
+    return true;
 }
 
 // exact norms of the flagged columns below row `row0` (?laqps: VN1 = VN2 = ?nrm2 after the block update)
@@ -1343,7 +1475,7 @@ BlockedQrcpJob<T> *qrb_begin(rc_context *c, Mat<T> w, int64_t kmax, int64_t *jpv
     P.st = J->st;
     J->vp = colmajor(c->alloc<T>((size_t)even_ld(m) * kNB), m, kNB, even_ld(m));
     J->ldy = even_ld(n);
-    J->Y = c->alloc<T>((size_t)kNB * J->ldy);
+    J->Y = c->alloc<T>((size_t)kQrbVtaMaxSplits * kNB * J->ldy);  // up to kQrbVtaMaxSplits partial slabs of kNB x ldy (k_qrb_vta); slab 0 alone for the GEMM path
     if (c->pinned_size < sizeof(QrbState)) {
         if (c->pinned) RC_HIP(hipHostFree(c->pinned));
         c->pinned = nullptr; c->pinned_size = 0;
@@ -1495,15 +1627,20 @@ bool qrb_finish(BlockedQrcpJob<T> *J) {
     Mat<T> w = J->w;
     Mat<T> vpp = Mat<T>(J->vp.p, rows, kb, 1, J->vp.cs);
     hipLaunchKernelGGL(k_qrb_build_vp<T>, dim3((unsigned)std::min<int64_t>(cdivb(rows, 256), 64), (unsigned)kb), dim3(256), 0, c->stream, w, (int)j0, J->st, vpp);
+    int ysplits = 1;
     if (h.have_noncand) {
-        // Y = V^T A(j0:m, :) for every column: one read pass (MFMA GEMM); used for the non-candidates only
-        Mat<T> ym = rowmajor(J->Y, kb, n, J->ldy);
-        gemm<T>(c, 1, vpp.t(), w.sub(j0, rows, 0, n), 0, ym);
+        // Y = V^T A(j0:m, :) for every column: one read pass; used for the non-candidates only.  f32 with 16-byte aligned columns: the
+        // streaming kernel k_qrb_vta (partial slabs, summed by k_qrb_finish); otherwise the MFMA GEMM
+        if (!qrb_vta_launch<T>(c, vpp, w.sub(j0, rows, 0, n), kb, J->Y, J->ldy, (int64_t)kNB * J->ldy, &ysplits)) {
+            ysplits = 1;
+            Mat<T> ym = rowmajor(J->Y, kb, n, J->ldy);
+            gemm<T>(c, 1, vpp.t(), w.sub(j0, rows, 0, n), 0, ym);
+        }
     }
     if (coop) hipLaunchKernelGGL(k_qrb_build_t<T>, dim3(1), dim3(1024), 0, c->stream, J->coop.D, J->tau, (int)j0, kb, J->Tm);
     else hipLaunchKernelGGL(k_qrb_scatter<T>, dim3((unsigned)cdivb(std::max(h.ncand, 1), 256)), dim3(256), 0, c->stream, w, (int)j0, kb, J->P, J->vn1);
     hipLaunchKernelGGL(k_qrb_finish<T>, dim3((unsigned)cdivb(n, 256)), dim3(256), 0, c->stream, w, (int)j0, kb, J->pos, J->is_cand, J->vn1, J->vn2, J->Fm, J->Y, J->ldy,
-                       J->Tm, vpp, J->flag, coop ? 1 : 0);
+                       J->Tm, vpp, J->flag, coop ? 1 : 0, ysplits, (int64_t)kNB * J->ldy);
     if (!last && rows - kb > 0) {
         // block update of everything below the panel, written as the transposed product so that the lanes of the
         // MFMA accumulator run along the column-major matrix' contiguous dimension:
