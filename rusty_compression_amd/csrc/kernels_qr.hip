@@ -655,7 +655,8 @@ void trsm_upper(rc_context *c, Mat<T> t, Mat<T> b) {
 //       the product Q R11, which equals those columns up to rounding (src/qr.rs:287-288 "first_part"); forming Q (?orgqr: three
 //       GEMMs per panel) only to multiply it back with R11 was a third of the launches of a cfg5 matrix.
 // ---------------------------------------------------------------------------
-template <typename T>
+// FROM_R: w is the k x n factor R in pivoted order (r(i, p), any strides) instead of the ?geqp3-format matrix
+template <typename T, bool FROM_R>
 __global__ __launch_bounds__(256) void k_id_z(Mat<T> w, const int64_t *jpvt, int64_t k, Mat<T> z) {
     constexpr int NB = 16;
     __shared__ T tile[NB][NB + 1];
@@ -664,7 +665,8 @@ __global__ __launch_bounds__(256) void k_id_z(Mat<T> w, const int64_t *jpvt, int
     const bool inside = p < n;
     const int64_t dc = inside ? jpvt[p] : 0;                            // where column p of [I | R11^-1 R12] goes
     const bool active = inside && p >= k;                               // a right-hand side (the first k columns are the identity)
-    const T *bcol = w.p + dc * w.cs;                                    // R12[:, p] = rows 0 .. k-1 of the physical column
+    const T *bcol = FROM_R ? w.p + (inside ? p : 0) * w.cs : w.p + dc * w.cs;  // R12[:, p] (rows 0 .. k-1 of the physical column)
+    const int64_t brs = FROM_R ? w.rs : 1;
     const int64_t nblk = (k + NB - 1) / NB;
     const int ti = threadIdx.x / NB, tj = threadIdx.x % NB;
     if (inside && p < k)
@@ -673,13 +675,13 @@ __global__ __launch_bounds__(256) void k_id_z(Mat<T> w, const int64_t *jpvt, int
         const int64_t r0 = bi * NB;
         T acc[NB];
 #pragma unroll
-        for (int ii = 0; ii < NB; ++ii) acc[ii] = (active && r0 + ii < k) ? bcol[r0 + ii] : (T)0;
+        for (int ii = 0; ii < NB; ++ii) acc[ii] = (active && r0 + ii < k) ? bcol[(r0 + ii) * brs] : (T)0;
         for (int64_t bj = nblk - 1; bj >= bi; --bj) {
             const int64_t c0 = bj * NB;
             __syncthreads();
             {
                 const int64_t i = r0 + ti, l = c0 + tj;
-                tile[ti][tj] = (i < k && l < k && i <= l) ? w.p[jpvt[l] * w.cs + i] : (T)0;
+                tile[ti][tj] = (i < k && l < k && i <= l) ? (FROM_R ? w.at(i, l) : w.p[jpvt[l] * w.cs + i]) : (T)0;
             }
             __syncthreads();
             if (bj > bi) {
@@ -716,12 +718,22 @@ void column_id_from_qrcp(rc_context *c, Mat<T> a, Mat<T> w, int64_t k, const int
                RC_INVALID_ARGUMENT, "column_id_from_qrcp: shape mismatch");
     if (a.cols == 0 || k == 0) return;
     ProfScope ps(c, "op:column_id_from_qrcp %lldx%lld k=%lld", (long long)a.rows, (long long)a.cols, (long long)k);
-    hipLaunchKernelGGL(k_id_z<T>, dim3((unsigned)cdiv(a.cols, 256)), dim3(256), 0, c->stream, w, jpvt, k, z);
+    hipLaunchKernelGGL((k_id_z<T, false>), dim3((unsigned)cdiv(a.cols, 256)), dim3(256), 0, c->stream, w, jpvt, k, z);
     gather_cols(c, a, jpvt, cm);  // C[:, i] = A[:, jpvt[i]], i < k
+}
+// Z = [I | R11^-1 R12] P^T from the k x n factor r (pivoted order) in one launch: the bits of
+// fill_identity + copy + trsm_upper + invert_perm + gather_cols (qr_column_id's former chain)
+template <typename T>
+void id_z_from_r(rc_context *c, Mat<T> r, int64_t k, const int64_t *ind, Mat<T> z) {
+    RC_REQUIRE(r.rows == k && z.rows == k && z.cols == r.cols && k <= r.cols, RC_INVALID_ARGUMENT, "id_z_from_r: shape mismatch");
+    if (r.cols == 0 || k == 0) return;
+    ProfScope ps(c, "op:id_z_from_r k=%lld n=%lld", (long long)k, (long long)r.cols);
+    hipLaunchKernelGGL((k_id_z<T, true>), dim3((unsigned)cdiv(r.cols, 256)), dim3(256), 0, c->stream, r, ind, k, z);
 }
 
 #define RC_INST(T)                                                                                         \
     template void column_id_from_qrcp<T>(rc_context *, Mat<T>, Mat<T>, int64_t, const int64_t *, Mat<T>, Mat<T>); \
+    template void id_z_from_r<T>(rc_context *, Mat<T>, int64_t, const int64_t *, Mat<T>);                 \
     template void geqp3_inplace<T>(rc_context *, Mat<T>, int64_t, bool, int64_t *, T *, T *);             \
     template void extract_r<T>(rc_context *, Mat<T>, const int64_t *, Mat<T>);                             \
     template void form_q<T>(rc_context *, Mat<T>, const int64_t *, const T *, int64_t, Mat<T>);           \

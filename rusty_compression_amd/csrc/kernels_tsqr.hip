@@ -223,17 +223,18 @@ bool tsqr_supported(int64_t m, int64_t n) {
     return n >= 2 && m >= 4 * n && m >= 1024 && small_lds <= 160 * 1024 - 2048;
 }
 
-// Y = Q R by CholeskyQR2.  y: m x n (any strides, not modified), q: m x n (any strides),
-// r: n x n (upper, any strides).  *flag (device int) gets bits OR-ed in on failure.
+// Y = Q R by CholeskyQR2 with Q left in factored form: Q = q1 r2i.  y: m x n (any strides, not modified), q1: m x n (row-major
+// for coalesced GEMM epilogues), r2i: n x n, r: n x n (upper, any strides).  *flag (device int) gets bits OR-ed in on failure.
+// Callers fold r2i into whatever small matrix multiplies Q next (Q2 of the small QRCP, U_c / V_c of the small SVD), so the
+// tall matrix is read by two Gram products and written / read by two applications instead of three (four with the sign pass).
 template <typename T>
-void tsqr_cholqr2(rc_context *c, Mat<T> y, Mat<T> q, Mat<T> r, int *flag) {
+void tsqr_cholqr2_factored(rc_context *c, Mat<T> y, Mat<T> q1, Mat<T> r2i, Mat<T> r, int *flag) {
     const int64_t m = y.rows, n = y.cols;
     ProfScope ps(c, "op:cholqr2 %lldx%lld", (long long)m, (long long)n);
     ArenaMark mark(c);
     Mat<T> g = rowmajor(c->alloc<T>((size_t)n * even_ld(n)), n, n, even_ld(n));
     Mat<T> r1 = rowmajor(c->alloc<T>((size_t)n * even_ld(n)), n, n, even_ld(n)), r1i = rowmajor(c->alloc<T>((size_t)n * even_ld(n)), n, n, even_ld(n));
-    Mat<T> r2 = rowmajor(c->alloc<T>((size_t)n * even_ld(n)), n, n, even_ld(n)), r2i = rowmajor(c->alloc<T>((size_t)n * even_ld(n)), n, n, even_ld(n));
-    Mat<T> q1 = rowmajor(c->alloc<T>((size_t)m * even_ld(n)), m, n, even_ld(n));  // row-major: coalesced GEMM epilogues
+    Mat<T> r2 = rowmajor(c->alloc<T>((size_t)n * even_ld(n)), n, n, even_ld(n));
     gemm<T>(c, 1, y.t(), y, 0, g);
     chol_inv<T>(c, g, r1, r1i, false, 0, 0, flag);
     gemm<T>(c, 1, y, r1i, 0, q1);
@@ -242,8 +243,18 @@ void tsqr_cholqr2(rc_context *c, Mat<T> y, Mat<T> q, Mat<T> r, int *flag) {
     static const int skip_ok = [] { const char *e = getenv("RC_CHOLQR_SKIP"); return e ? atoi(e) : 1; }();
     const T skip_tol = skip_ok ? (sizeof(T) == 8 ? (T)2.5e-14 : (T)1e-6) : (T)-1;
     chol_inv<T>(c, g, r2, r2i, true, (T)1e-2, skip_tol, flag);
-    gemm<T>(c, 1, q1, r2i, 0, q);
     gemm<T>(c, 1, r2, r1, 0, r);
+}
+
+// Y = Q R with Q formed: q m x n (any strides)
+template <typename T>
+void tsqr_cholqr2(rc_context *c, Mat<T> y, Mat<T> q, Mat<T> r, int *flag) {
+    const int64_t m = y.rows, n = y.cols;
+    ArenaMark mark(c);
+    Mat<T> q1 = rowmajor(c->alloc<T>((size_t)m * even_ld(n)), m, n, even_ld(n));
+    Mat<T> r2i = rowmajor(c->alloc<T>((size_t)n * even_ld(n)), n, n, even_ld(n));
+    tsqr_cholqr2_factored<T>(c, y, q1, r2i, r, flag);
+    gemm<T>(c, 1, q1, r2i, 0, q);
 }
 
 // ---------------------------------------------------------------------------
@@ -531,48 +542,77 @@ __global__ __launch_bounds__(256) void k_scale_cols_rows(Mat<T> q, Mat<T> r, con
     }
 }
 
+// d_j of the sign convention from the top k x k block of Q (k x k, any strides)
 template <typename T>
-void householder_sign_fix(rc_context *c, Mat<T> q, Mat<T> r) {
-    const int64_t k = q.cols;
-    if (k == 0) return;
-    RC_REQUIRE(q.rows >= k, RC_INVALID_ARGUMENT, "sign fix: q must be tall");
+static void householder_signs(rc_context *c, Mat<T> top, T *d) {
+    const int64_t k = top.cols;
     const size_t lds = (size_t)k * (k | 1) * sizeof(T);
-    RC_REQUIRE(lds <= 160 * 1024 - 1024, RC_INVALID_ARGUMENT, "sign fix: k = %lld does not fit LDS", (long long)k);
-    ProfScope ps(c, "op:householder_sign_fix k=%lld", (long long)k);
-    ArenaMark mark(c);
-    T *d = c->alloc<T>((size_t)k);
+    RC_REQUIRE(top.rows >= k && lds <= 160 * 1024 - 1024, RC_INVALID_ARGUMENT, "sign fix: k = %lld does not fit LDS", (long long)k);
     auto kern = k_householder_signs<T>;
     static bool attr_set[64] = {};
     if (!attr_set[c->device & 63]) {
         RC_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024));
         attr_set[c->device & 63] = true;
     }
-    hipLaunchKernelGGL(kern, dim3(1), dim3(1024), lds, c->stream, q, d);
+    hipLaunchKernelGGL(kern, dim3(1), dim3(1024), lds, c->stream, top, d);
+}
+template <typename T>
+static void scale_cols_rows(rc_context *c, Mat<T> q, Mat<T> r, const T *d) {
     const int64_t total = q.rows * q.cols + r.rows * r.cols;
     hipLaunchKernelGGL(k_scale_cols_rows<T>, dim3((unsigned)std::min<int64_t>(cdiv(total, 256), 4096)), dim3(256), 0, c->stream, q, r, d);
 }
 
+template <typename T>
+void householder_sign_fix(rc_context *c, Mat<T> q, Mat<T> r) {
+    const int64_t k = q.cols;
+    if (k == 0) return;
+    RC_REQUIRE(q.rows >= k, RC_INVALID_ARGUMENT, "sign fix: q must be tall");
+    ProfScope ps(c, "op:householder_sign_fix k=%lld", (long long)k);
+    ArenaMark mark(c);
+    T *d = c->alloc<T>((size_t)k);
+    householder_signs<T>(c, q, d);
+    scale_cols_rows<T>(c, q, r, d);
+}
+
 // Pivoted (or plain) QR of the tall-skinny y through CholeskyQR2 + small QRCP + sign fix.
 //   q: m x k column-major (may be empty), r: k x n (may be empty), ind: n
+// Q = Q1 (R2^-1 Q2 D): the n x k factor W = R2^-1 Q2 is formed first, the signs D (+-1: exact) come from the top k x k block
+// Q1[:k, :] W and go into W's columns and R's rows, and ONE tall product writes Q.  (Until round 3: Q1 R2^-1, then (.) Q2, then a
+// sign pass over Q: two more passes over the tall matrix; RC_TSQR_FOLD=0 restores that order.)
 template <typename T>
 void qrcp_tall_fast(rc_context *c, Mat<T> y, int64_t k, bool pivot, Mat<T> q, Mat<T> r, int64_t *ind, int *flag) {
     const int64_t m = y.rows, n = y.cols;
     ProfScope ps(c, "op:qrcp_tall_fast %lldx%lld k=%lld pivot=%d", (long long)m, (long long)n, (long long)k, pivot ? 1 : 0);
     ArenaMark mark(c);
+    static const int fold = [] { const char *e = getenv("RC_TSQR_FOLD"); return e ? atoi(e) : 1; }();
     Mat<T> q1 = rowmajor(c->alloc<T>((size_t)m * even_ld(n)), m, n, even_ld(n));
     Mat<T> r1 = colmajor(c->alloc<T>((size_t)n * even_ld(n)), n, n, even_ld(n));
-    tsqr_cholqr2<T>(c, y, q1, r1, flag);
+    Mat<T> r2i = rowmajor(c->alloc<T>((size_t)n * even_ld(n)), n, n, even_ld(n));
+    if (fold) tsqr_cholqr2_factored<T>(c, y, q1, r2i, r1, flag);
+    else tsqr_cholqr2<T>(c, y, q1, r1, flag);
     Mat<T> q2 = colmajor(c->alloc<T>((size_t)even_ld(n) * k), n, k, even_ld(n));
     Mat<T> rr = r.empty() ? rowmajor(c->alloc<T>((size_t)k * even_ld(n)), k, n, even_ld(n)) : r;
     qrcp_small<T>(c, r1, k, pivot, ind, rr, q2);
     Mat<T> qq = q.empty() ? rowmajor(c->alloc<T>((size_t)m * even_ld(k)), m, k, even_ld(k)) : q;
-    gemm<T>(c, 1, q1, q2, 0, qq);
-    householder_sign_fix<T>(c, qq, rr);
+    if (!fold) {
+        gemm<T>(c, 1, q1, q2, 0, qq);
+        householder_sign_fix<T>(c, qq, rr);
+        return;
+    }
+    Mat<T> w = colmajor(c->alloc<T>((size_t)even_ld(n) * k), n, k, even_ld(n));
+    Mat<T> top = colmajor(c->alloc<T>((size_t)even_ld(k) * k), k, k, even_ld(k));
+    T *d = c->alloc<T>((size_t)k);
+    gemm<T>(c, 1, r2i, q2, 0, w);
+    gemm<T>(c, 1, q1.sub(0, k, 0, n), w, 0, top);
+    householder_signs<T>(c, top, d);
+    scale_cols_rows<T>(c, w, rr, d);
+    gemm<T>(c, 1, q1, w, 0, qq);
 }
 
 #define RC_INST(T)                                                                                               \
     template bool tsqr_supported<T>(int64_t, int64_t);                                                           \
     template void tsqr_cholqr2<T>(rc_context *, Mat<T>, Mat<T>, Mat<T>, int *);                                  \
+    template void tsqr_cholqr2_factored<T>(rc_context *, Mat<T>, Mat<T>, Mat<T>, Mat<T>, int *);                 \
     template void qrcp_small<T>(rc_context *, Mat<T>, int64_t, bool, int64_t *, Mat<T>, Mat<T>);                 \
     template void householder_sign_fix<T>(rc_context *, Mat<T>, Mat<T>);                                         \
     template void qrcp_tall_fast<T>(rc_context *, Mat<T>, int64_t, bool, Mat<T>, Mat<T>, int64_t *, int *);

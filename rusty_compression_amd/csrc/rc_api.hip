@@ -386,13 +386,24 @@ void svd_core(rc_context *c, Mat<T> wt, bool transposed, Mat<T> u, T *s, Mat<T> 
     const int64_t M = wt.rows, r = wt.cols;
     ArenaMark mark(c);
     Mat<T> core = tmp_colmajor<T>(c, r, r);
-    Mat<T> qw = tmp_colmajor<T>(c, M, r);
+    Mat<T> qw, q1, r2i;
     bool done = false;
+    static const int fold = [] { const char *e = getenv("RC_TSQR_FOLD"); return e ? atoi(e) : 1; }();
     if (c->opt_tsqr && tsqr_supported<T>(M, r)) {
-        // tall: core = R ; wide: core = L = R^T  (a = L Q_w^T)
-        done = run_certified(c, [&](int *flag) { tsqr_cholqr2<T>(c, wt, qw, transposed ? core.t() : core, flag); });
+        // tall: core = R ; wide: core = L = R^T  (a = L Q_w^T).  Q_w stays factored (Q1 R2^-1): R2^-1 goes into the small
+        // factor that multiplies Q_w below, one pass over the tall matrix less
+        if (fold) {
+            q1 = rowmajor(c->alloc<T>((size_t)M * even_ld(r)), M, r, even_ld(r));
+            r2i = rowmajor(c->alloc<T>((size_t)r * even_ld(r)), r, r, even_ld(r));
+            done = run_certified(c, [&](int *flag) { tsqr_cholqr2_factored<T>(c, wt, q1, r2i, transposed ? core.t() : core, flag); });
+        } else {
+            qw = tmp_colmajor<T>(c, M, r);
+            done = run_certified(c, [&](int *flag) { tsqr_cholqr2<T>(c, wt, qw, transposed ? core.t() : core, flag); });
+        }
     }
+    const bool factored = done && fold;
     if (!done) {
+        qw = tmp_colmajor<T>(c, M, r);
         int64_t *jp = c->alloc<int64_t>((size_t)std::max<int64_t>(r, 1));
         T *tau = c->alloc<T>((size_t)std::max<int64_t>(r, 1));
         T *vn = c->alloc<T>((size_t)std::max<int64_t>(2 * r, 1));
@@ -403,14 +414,21 @@ void svd_core(rc_context *c, Mat<T> wt, bool transposed, Mat<T> u, T *s, Mat<T> 
     Mat<T> vwork = tmp_colmajor<T>(c, r, r), uc = tmp_colmajor<T>(c, r, r), vc = tmp_colmajor<T>(c, r, r);
     jacobi_svd(c, core, vwork, uc, s, vc);
     complete_left_basis(c, uc, s);  // (?gesdd: U stays orthonormal when singular values are zero; no-op otherwise)
+    Mat<T> small;
+    if (factored) {
+        small = tmp_colmajor<T>(c, r, r);
+        gemm<T>(c, 1, r2i, transposed ? vc : uc, 0, small);
+    }
     if (!transposed) {
         // a = Q_w R = (Q_w Uc) S Vc^T
-        gemm<T>(c, 1, qw, uc, 0, u);
+        if (factored) gemm<T>(c, 1, q1, small, 0, u);
+        else gemm<T>(c, 1, qw, uc, 0, u);
         copy_mat(c, vc.t(), vt);
     } else {
         // a = L Q_w^T = Uc S (Q_w Vc)^T
         copy_mat(c, uc, u);
-        gemm<T>(c, 1, vc.t(), qw.t(), 0, vt);
+        if (factored) gemm<T>(c, 1, small.t(), q1.t(), 0, vt);
+        else gemm<T>(c, 1, vc.t(), qw.t(), 0, vt);
     }
 }
 
@@ -440,6 +458,13 @@ void qr_column_id(rc_context *c, Mat<T> q, Mat<T> r, const int64_t *ind, Mat<T> 
     RC_REQUIRE(k <= n, RC_INVALID_ARGUMENT, "column_id: rank exceeds the number of columns");
     if (n == 0) return;
     ArenaMark mark(c);
+    static const int fused = [] { const char *e = getenv("RC_ID_FUSED"); return e ? atoi(e) : 1; }();
+    if (fused && k < n) {
+        // Z in ONE launch (k_id_z: the chain below with the same arithmetic, every column written to its final place)
+        id_z_from_r(c, r, k, ind, z);
+        gemm<T>(c, 1, q, r.sub(0, k, 0, k), 0, cm);
+        return;
+    }
     int64_t *inv = c->alloc<int64_t>((size_t)n);
     invert_perm(c, ind, n, inv);
     Mat<T> zt = tmp_rowmajor<T>(c, k, n);

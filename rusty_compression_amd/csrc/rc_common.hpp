@@ -198,6 +198,7 @@ template <typename T> void scale_rows(rc_context *c, const T *s, Mat<T> src, Mat
 template <typename T> void gather_cols(rc_context *c, Mat<T> src, const int64_t *idx, Mat<T> dst);  // dst[:, j] = src[:, idx[j]]
 // C, Z of the rank-k column ID from the ?geqp3-format factorization w of a (kernels_qr.hip: two launches, no Q)
 template <typename T> void column_id_from_qrcp(rc_context *c, Mat<T> a, Mat<T> w, int64_t k, const int64_t *jpvt, Mat<T> cm, Mat<T> z);
+template <typename T> void id_z_from_r(rc_context *c, Mat<T> r, int64_t k, const int64_t *ind, Mat<T> z);
 void invert_perm(rc_context *c, const int64_t *perm, int64_t n, int64_t *inv);
 void fill_words(rc_context *c, void *p, size_t bytes, unsigned v);  // every 32-bit word of [p, p + bytes) = v, by a kernel on c->stream (no hipMemset*)
 void iota_i64(rc_context *c, int64_t *p, int64_t n);
@@ -252,6 +253,7 @@ template <typename T> void trsm_upper(rc_context *c, Mat<T> t, Mat<T> b);
 // tall-skinny fast path (kernels_tsqr.hip): CholeskyQR2 + LDS-resident QRCP + Householder sign fix
 template <typename T> bool tsqr_supported(int64_t m, int64_t n);
 template <typename T> void tsqr_cholqr2(rc_context *c, Mat<T> y, Mat<T> q, Mat<T> r, int *flag);
+template <typename T> void tsqr_cholqr2_factored(rc_context *c, Mat<T> y, Mat<T> q1, Mat<T> r2i, Mat<T> r, int *flag);
 template <typename T> void qrcp_small(rc_context *c, Mat<T> rin, int64_t kmax, bool pivot, int64_t *jpvt, Mat<T> rout, Mat<T> q2);
 template <typename T> void householder_sign_fix(rc_context *c, Mat<T> q, Mat<T> r);
 template <typename T> void qrcp_tall_fast(rc_context *c, Mat<T> y, int64_t k, bool pivot, Mat<T> q, Mat<T> r, int64_t *ind, int *flag);
