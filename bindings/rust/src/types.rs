@@ -49,6 +49,10 @@ pub trait Scalar:
     unsafe fn ffi_pivoted_qr(ctx: *mut rc_context, a: rc_matrix, q: rc_matrix, r: rc_matrix, ind: *mut i64) -> rc_status;
     unsafe fn ffi_pivoted_lq(ctx: *mut rc_context, a: rc_matrix, l: rc_matrix, q: rc_matrix, ind: *mut i64) -> rc_status;
     unsafe fn ffi_compute_svd(ctx: *mut rc_context, a: rc_matrix, u: rc_matrix, s: *mut Self::Real, vt: rc_matrix) -> rc_status;
+    /// the LAPACK seam (`$qrf` at reference `src/pivoted_qr.rs:139-172`, `lax::Lapack::q` at `:104-108`, `solve_triangular` at `src/qr.rs:298`)
+    unsafe fn ffi_geqp3(ctx: *mut rc_context, a: rc_matrix, kmax: i64, jpvt: *mut i64, tau: *mut std::os::raw::c_void) -> rc_status;
+    unsafe fn ffi_orgqr(ctx: *mut rc_context, a: rc_matrix, tau: *const std::os::raw::c_void, k: i64, q: rc_matrix) -> rc_status;
+    unsafe fn ffi_trsm_upper(ctx: *mut rc_context, t: rc_matrix, b: rc_matrix) -> rc_status;
     unsafe fn ffi_qr_to_mat(ctx: *mut rc_context, q: rc_matrix, r: rc_matrix, ind: *const i64, out: rc_matrix) -> rc_status;
     unsafe fn ffi_lq_to_mat(ctx: *mut rc_context, l: rc_matrix, q: rc_matrix, ind: *const i64, out: rc_matrix) -> rc_status;
     unsafe fn ffi_qr_column_id(ctx: *mut rc_context, q: rc_matrix, r: rc_matrix, ind: *const i64, c: rc_matrix, z: rc_matrix) -> rc_status;
@@ -86,6 +90,9 @@ macro_rules! impl_scalar {
             unsafe fn ffi_pivoted_qr(ctx: *mut rc_context, a: rc_matrix, q: rc_matrix, r: rc_matrix, ind: *mut i64) -> rc_status { [<rc_pivoted_qr_ $suf>](ctx, a, q, r, ind) }
             unsafe fn ffi_pivoted_lq(ctx: *mut rc_context, a: rc_matrix, l: rc_matrix, q: rc_matrix, ind: *mut i64) -> rc_status { [<rc_pivoted_lq_ $suf>](ctx, a, l, q, ind) }
             unsafe fn ffi_compute_svd(ctx: *mut rc_context, a: rc_matrix, u: rc_matrix, s: *mut $real, vt: rc_matrix) -> rc_status { [<rc_compute_svd_ $suf>](ctx, a, u, s, vt) }
+            unsafe fn ffi_geqp3(ctx: *mut rc_context, a: rc_matrix, kmax: i64, jpvt: *mut i64, tau: *mut std::os::raw::c_void) -> rc_status { [<rc_geqp3_ $suf>](ctx, a, kmax, jpvt, tau as *mut _) }
+            unsafe fn ffi_orgqr(ctx: *mut rc_context, a: rc_matrix, tau: *const std::os::raw::c_void, k: i64, q: rc_matrix) -> rc_status { [<rc_orgqr_ $suf>](ctx, a, tau as *const _, k, q) }
+            unsafe fn ffi_trsm_upper(ctx: *mut rc_context, t: rc_matrix, b: rc_matrix) -> rc_status { [<rc_trsm_upper_ $suf>](ctx, t, b) }
             unsafe fn ffi_qr_to_mat(ctx: *mut rc_context, q: rc_matrix, r: rc_matrix, ind: *const i64, out: rc_matrix) -> rc_status { [<rc_qr_to_mat_ $suf>](ctx, q, r, ind, out) }
             unsafe fn ffi_lq_to_mat(ctx: *mut rc_context, l: rc_matrix, q: rc_matrix, ind: *const i64, out: rc_matrix) -> rc_status { [<rc_lq_to_mat_ $suf>](ctx, l, q, ind, out) }
             unsafe fn ffi_qr_column_id(ctx: *mut rc_context, q: rc_matrix, r: rc_matrix, ind: *const i64, c: rc_matrix, z: rc_matrix) -> rc_status { [<rc_qr_column_id_ $suf>](ctx, q, r, ind, c, z) }

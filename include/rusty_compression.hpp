@@ -104,6 +104,9 @@ template <typename T> struct Api;
         static constexpr auto apply_permutation_matrix = rc_apply_permutation_matrix_##SUF;                         \
         static constexpr auto pivoted_qr = rc_pivoted_qr_##SUF;                                                     \
         static constexpr auto pivoted_lq = rc_pivoted_lq_##SUF;                                                     \
+        static constexpr auto geqp3 = rc_geqp3_##SUF;                                                               \
+        static constexpr auto orgqr = rc_orgqr_##SUF;                                                               \
+        static constexpr auto trsm_upper = rc_trsm_upper_##SUF;                                                     \
         static constexpr auto compute_svd = rc_compute_svd_##SUF;                                                   \
         static constexpr auto rank_by_tolerance = rc_rank_by_tolerance_##SUF;                                       \
         static constexpr auto qr_to_mat = rc_qr_to_mat_##SUF;                                                       \
@@ -252,6 +255,37 @@ DeviceMatrix<T> random_gaussian(const Context &ctx, int64_t rows, int64_t cols, 
 template <typename T> struct ColumnID;
 template <typename T> struct RowID;
 template <typename T> struct TwoSidedID;
+
+// ---- the LAPACK seam: what the reference calls per factorization ($qrf = ?geqp3 at src/pivoted_qr.rs:139-172, lax::Lapack::q =
+// ?orgqr / ?ungqr at :104-108, solve_triangular = ?trtrs at src/qr.rs:298, :392), in LAPACK's own formats ----------------------
+template <typename T>
+struct Geqp3 {
+    DeviceMatrix<T> a;        // the factored A P: R on / above the diagonal, Householder vectors below it (columns in pivoted order)
+    DeviceIndex jpvt;         // 0-based
+    DeviceBuffer<T> tau;
+};
+template <typename T>
+Geqp3<T> geqp3(const DeviceMatrix<T> &mat, int64_t kmax = -1) {
+    const int64_t m = mat.nrows(), n = mat.ncols();
+    if (kmax < 0) kmax = m < n ? m : n;
+    Geqp3<T> out{clone_matrix(mat), DeviceIndex(mat.ctx(), (std::size_t)n), DeviceBuffer<T>(mat.ctx(), (std::size_t)(kmax > 0 ? kmax : 1))};
+    using wire_t = decltype(Scalar<T>::wire(T()));
+    mat.ctx().check(Api<T>::geqp3(mat.ctx().raw(), out.a.view(), kmax, out.jpvt.data(), reinterpret_cast<wire_t *>(out.tau.data())));
+    return out;
+}
+template <typename T>
+DeviceMatrix<T> orgqr(const Geqp3<T> &f, int64_t k) {
+    using wire_t = decltype(Scalar<T>::wire(T()));
+    DeviceMatrix<T> q(f.a.ctx(), f.a.nrows(), k);
+    f.a.ctx().check(Api<T>::orgqr(f.a.ctx().raw(), f.a.view(), reinterpret_cast<const wire_t *>(f.tau.data()), k, q.view()));
+    return q;
+}
+template <typename T>
+DeviceMatrix<T> trsm_upper(const DeviceMatrix<T> &t, const DeviceMatrix<T> &b) {  // returns X with T X = B
+    DeviceMatrix<T> x = clone_matrix(b);
+    t.ctx().check(Api<T>::trsm_upper(t.ctx().raw(), t.view(), x.view()));
+    return x;
+}
 
 // ---- qr.rs ---------------------------------------------------------------------------------------
 template <typename T>

@@ -238,6 +238,22 @@ rc_status rc_pivoted_qr_f32(rc_context *ctx, rc_matrix a, rc_matrix q, rc_matrix
 rc_status rc_pivoted_lq_f64(rc_context *ctx, rc_matrix a, rc_matrix l, rc_matrix q, int64_t *ind);
 rc_status rc_pivoted_lq_f32(rc_context *ctx, rc_matrix a, rc_matrix l, rc_matrix q, int64_t *ind);
 
+/* LAPACK granularity, for a maintainer who swaps only the `$qrf` call (src/pivoted_qr.rs:139-172, ?geqp3), `lax::Lapack::q`
+ * (src/pivoted_qr.rs:104-108, ?orgqr / ?ungqr) or the triangular solves of the IDs (src/qr.rs:298, :392, ?trtrs) and keeps the
+ * reference's own code around them.  All pointers are DEVICE pointers.
+ * rc_geqp3: a (m x n, any strides) is overwritten with LAPACK's output format -- the factorization of A P, columns in pivoted order:
+ *   R on and above the diagonal of the first kmax rows, Householder vectors below it in the first kmax columns; jpvt (n, 0-based:
+ *   LAPACK's minus one), tau (kmax).  kmax == min(m, n) is ?geqp3; kmax < min(m, n) stops after kmax steps (rows >= kmax of the
+ *   columns >= kmax are then unspecified).
+ * rc_orgqr: q (m x k) = H_0 ... H_{k-1} [I; 0] from the first k columns of such an a and tau.
+ * rc_trsm_upper: T X = B in place (t: k x k upper triangular, b: k x nrhs); no singularity check (?trtrs' INFO is not reproduced). */
+rc_status rc_geqp3_f64(rc_context *ctx, rc_matrix a, int64_t kmax, int64_t *jpvt, double *tau);
+rc_status rc_geqp3_f32(rc_context *ctx, rc_matrix a, int64_t kmax, int64_t *jpvt, float *tau);
+rc_status rc_orgqr_f64(rc_context *ctx, rc_matrix a, const double *tau, int64_t k, rc_matrix q);
+rc_status rc_orgqr_f32(rc_context *ctx, rc_matrix a, const float *tau, int64_t k, rc_matrix q);
+rc_status rc_trsm_upper_f64(rc_context *ctx, rc_matrix t, rc_matrix b);
+rc_status rc_trsm_upper_f32(rc_context *ctx, rc_matrix t, rc_matrix b);
+
 /* ---------------------------------------------------------- compute_svd.rs -- */
 /* ComputeSVD::compute_svd (src/compute_svd.rs:18-27) = thin ?gesdd:
  *   u: m x r, s: r (device, descending), vt: r x n, r = min(m, n).
@@ -477,6 +493,9 @@ rc_status rc_apply_permutation_matrix_c64(rc_context *ctx, int32_t mode, rc_matr
 rc_status rc_apply_permutation_vector_c64(rc_context *ctx, int32_t mode, rc_matrix in, const int64_t *perm, int64_t perm_len, rc_matrix out);
 rc_status rc_pivoted_qr_c64(rc_context *ctx, rc_matrix a, rc_matrix q, rc_matrix r, int64_t *ind);
 rc_status rc_pivoted_lq_c64(rc_context *ctx, rc_matrix a, rc_matrix l, rc_matrix q, int64_t *ind);
+rc_status rc_geqp3_c64(rc_context *ctx, rc_matrix a, int64_t kmax, int64_t *jpvt, rc_complex64 *tau);   /* ?geqp3, LAPACK format (see rc_geqp3_f64) */
+rc_status rc_orgqr_c64(rc_context *ctx, rc_matrix a, const rc_complex64 *tau, int64_t k, rc_matrix q);   /* ?ungqr */
+rc_status rc_trsm_upper_c64(rc_context *ctx, rc_matrix t, rc_matrix b);
 rc_status rc_compute_svd_c64(rc_context *ctx, rc_matrix a, rc_matrix u, double *s, rc_matrix vt);
 rc_status rc_rank_by_tolerance_c64(rc_context *ctx, rc_matrix tri, double tol, int64_t *rank);
 rc_status rc_qr_to_mat_c64(rc_context *ctx, rc_matrix q, rc_matrix r, const int64_t *ind, rc_matrix out);
@@ -512,6 +531,9 @@ rc_status rc_apply_permutation_matrix_c32(rc_context *ctx, int32_t mode, rc_matr
 rc_status rc_apply_permutation_vector_c32(rc_context *ctx, int32_t mode, rc_matrix in, const int64_t *perm, int64_t perm_len, rc_matrix out);
 rc_status rc_pivoted_qr_c32(rc_context *ctx, rc_matrix a, rc_matrix q, rc_matrix r, int64_t *ind);
 rc_status rc_pivoted_lq_c32(rc_context *ctx, rc_matrix a, rc_matrix l, rc_matrix q, int64_t *ind);
+rc_status rc_geqp3_c32(rc_context *ctx, rc_matrix a, int64_t kmax, int64_t *jpvt, rc_complex32 *tau);   /* ?geqp3, LAPACK format (see rc_geqp3_f64) */
+rc_status rc_orgqr_c32(rc_context *ctx, rc_matrix a, const rc_complex32 *tau, int64_t k, rc_matrix q);   /* ?ungqr */
+rc_status rc_trsm_upper_c32(rc_context *ctx, rc_matrix t, rc_matrix b);
 rc_status rc_compute_svd_c32(rc_context *ctx, rc_matrix a, rc_matrix u, float *s, rc_matrix vt);
 rc_status rc_rank_by_tolerance_c32(rc_context *ctx, rc_matrix tri, double tol, int64_t *rank);
 rc_status rc_qr_to_mat_c32(rc_context *ctx, rc_matrix q, rc_matrix r, const int64_t *ind, rc_matrix out);

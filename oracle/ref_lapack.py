@@ -233,6 +233,33 @@ def pivoted_qr(arr: np.ndarray):
     return q, np.ascontiguousarray(r), ind
 
 
+def geqp3_raw(arr: np.ndarray):
+    """The `$qrf` call alone (src/pivoted_qr.rs:139-150, :161-172): returns (qr, jpvt0, tau) exactly as ?geqp3 leaves them
+    (qr = R on / above the diagonal and the Householder vectors below it, columns in pivoted order; jpvt0 = jpvt - 1, :177)."""
+    arr = np.asarray(arr)
+    qr_, jpvt, tau, work, info = _lp("geqp3", arr.dtype)(np.asfortranarray(arr.copy()), overwrite_a=1)
+    if info != 0:
+        raise PivotedQRError(info)
+    return qr_, jpvt.astype(np.int64) - 1, tau
+
+
+def orgqr_raw(qr_: np.ndarray, tau: np.ndarray) -> np.ndarray:
+    """`lax::Lapack::q` alone (src/pivoted_qr.rs:104-108): Q = H_0 ... H_{k-1} [I; 0], k = len(tau) columns."""
+    k = len(tau)
+    q_, work, info = _lp("orgqr", qr_.dtype)(np.asfortranarray(qr_[:, :k].copy()), tau)
+    if info != 0:
+        raise PivotedQRError(info)
+    return np.ascontiguousarray(q_[:, :k])
+
+
+def trtrs_upper(t: np.ndarray, b: np.ndarray) -> np.ndarray:
+    """`solve_triangular(UPLO::Upper, Diag::NonUnit, ..)` (src/qr.rs:298, :392) for all right-hand sides at once."""
+    x, info = _lp("trtrs", t.dtype)(np.asfortranarray(t), np.asfortranarray(b), lower=0, trans=0, unitdiag=0)
+    if info != 0:
+        raise LinalgError(info)
+    return np.ascontiguousarray(x)
+
+
 def pivoted_lq(arr: np.ndarray):
     """src/pivoted_qr.rs:32-41: pivoted QR of arr^H, transposed back. Returns (l, q, ind)."""
     q, r, ind = pivoted_qr(np.ascontiguousarray(_h(arr)))

@@ -19,6 +19,7 @@ from .random_sampling import (max_col_norm, sample_range_adaptive, sample_range_
                               sample_range_power_iteration)
 from .row_interp_decomp import RowID  # noqa: F401
 from .svd import SVD, compute_svd  # noqa: F401
+from .lapack import geqp3, orgqr, trsm_upper  # noqa: F401
 from .two_sided_interp_decomp import TwoSidedID  # noqa: F401
 from .types import CompressionType, conj_matmat, dot, matmat, rel_diff_fro, rel_diff_l2  # noqa: F401
 
@@ -27,7 +28,7 @@ __all__ = [
     "MatrixPermutationMode", "VectorPermutationMode", "apply_permutation", "invert_permutation_vector",
     "random_gaussian", "random_bits_u32", "random_orthogonal_matrix", "random_approximate_low_rank_matrix",
     "sample_range_by_rank", "sample_range_power_iteration", "sample_range_adaptive", "max_col_norm",
-    "matmat", "conj_matmat", "dot", "rel_diff_fro", "rel_diff_l2", "pivoted_qr", "pivoted_lq", "compute_svd",
+    "matmat", "conj_matmat", "dot", "rel_diff_fro", "rel_diff_l2", "pivoted_qr", "pivoted_lq", "compute_svd", "geqp3", "orgqr", "trsm_upper",
     "RustyCompressionError", "LinalgError", "CompressionError", "LayoutError", "PivotedQRError", "HipRuntimeError",
     "Context", "default_context", "Operator", "DenseOperator", "LowRankOperator",
 ]

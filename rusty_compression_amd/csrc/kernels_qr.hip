@@ -426,11 +426,15 @@ __global__ __launch_bounds__(256) void k_form_q_general(Mat<T> w, const int64_t 
         const T tj = tau[j];
         if (tj == (T)0) continue;
         const T *vcol = w.p + jpvt[j] * w.cs;
+        // thread tid owns the rows i = tid (mod 256) for the WHOLE kernel (the initialisation above included): x[i] is only ever
+        // touched by its owner, so no barrier is needed between a step's update and the next step's reads.  (Until round 3 the
+        // loops started at j + tid: the owner of a row changed from step to step without a barrier in between -- a race between waves.)
+        const int64_t i0 = tid >= j ? tid : tid + ((j - tid + 255) / 256) * 256;
         T dot = 0;
-        for (int64_t i = j + tid; i < m; i += 256) dot += ((i == j) ? (T)1 : vcol[i]) * x[i];  // same thread wrote x[i]
+        for (int64_t i = i0; i < m; i += 256) dot += ((i == j) ? (T)1 : vcol[i]) * x[i];
         dot = group_sum<T, 256>(dot, sh);
         const T f = tj * dot;
-        for (int64_t i = j + tid; i < m; i += 256) x[i] -= f * ((i == j) ? (T)1 : vcol[i]);
+        for (int64_t i = i0; i < m; i += 256) x[i] -= f * ((i == j) ? (T)1 : vcol[i]);
     }
 }
 

@@ -379,6 +379,64 @@ void pivoted_qr(rc_context *c, Mat<T> a, Mat<T> q, Mat<T> r, int64_t *ind) {
     qrcp_core(c, w, k, true, q, r, ind);
 }
 
+// ---- LAPACK granularity (for a maintainer who swaps only the `$qrf` call at /root/reference/src/pivoted_qr.rs:139-172
+// and `lax::q` at :104-108, or the `solve_triangular` calls at src/qr.rs:298, :392)
+// ?geqp3: a (m x n) is overwritten with LAPACK's output -- the factorization of A P with its columns IN pivoted order: R on and above
+// the diagonal of the first kmax rows, the Householder vectors below it in the first kmax columns; jpvt 0-based (device, n), tau
+// (device, kmax).  kmax == min(m, n) is ?geqp3; kmax < min(m, n) stops after kmax steps (rows >= kmax of the columns >= kmax are
+// then unspecified).
+template <typename T>
+void lapack_geqp3(rc_context *c, Mat<T> a, int64_t kmax, int64_t *jpvt, T *tau) {
+    const int64_t m = a.rows, n = a.cols;
+    RC_REQUIRE(kmax >= 0 && kmax <= std::min(m, n), RC_INVALID_ARGUMENT, "geqp3: need 0 <= kmax <= min(m, n)");
+    RC_REQUIRE(jpvt != nullptr && (kmax == 0 || tau != nullptr), RC_INVALID_ARGUMENT, "geqp3: null jpvt / tau");
+    if (n == 0) return;
+    if (kmax == 0 || m == 0) { iota_i64(c, jpvt, n); return; }
+    ArenaMark mark(c);
+    Mat<T> w = tmp_colmajor<T>(c, m, n);
+    copy_mat(c, a, w);
+    Mat<T> src = w;
+    bool done = false;
+    if (c->opt_wide_coop && wide_coop_supported<T>(m, n, c->device)) {
+        Mat<T> wf = tmp_colmajor<T>(c, m, n);
+        if (run_certified(c, [&](int *flag) { geqp3_wide_coop<T>(c, w, wf, kmax, jpvt, tau, flag); })) { src = wf; done = true; }
+    }
+    if (!done && c->opt_blocked && !c->capturing && geqp3_blocked_supported<T>(m, n, kmax)) {
+        geqp3_blocked<T>(c, w, kmax, jpvt, tau, Mat<T>());
+        done = true;
+    }
+    if (!done) {
+        T *vn = c->alloc<T>((size_t)std::max<int64_t>(2 * n, 1));
+        geqp3_inplace(c, w, kmax, true, jpvt, tau, vn);
+    }
+    gather_cols(c, src, jpvt, a);  // a[:, p] = factored column jpvt[p]
+}
+// ?orgqr: q (m x k) = H_0 ... H_{k-1} [I; 0] from the reflectors below the diagonal of the first k columns of a (LAPACK format) and tau
+template <typename T>
+void lapack_orgqr(rc_context *c, Mat<T> a, const T *tau, int64_t k, Mat<T> q) {
+    const int64_t m = a.rows;
+    RC_REQUIRE(k >= 0 && k <= std::min(m, a.cols) && q.rows == m && q.cols == k, RC_INVALID_ARGUMENT,
+               "orgqr: need k <= min(m, n) reflectors in a and q of m x k");
+    if (k == 0 || m == 0) return;
+    RC_REQUIRE(tau != nullptr, RC_INVALID_ARGUMENT, "orgqr: null tau");
+    ArenaMark mark(c);
+    int64_t *ident = c->alloc<int64_t>((size_t)k);
+    iota_i64(c, ident, k);
+    Mat<T> w = a.sub(0, m, 0, k);
+    if (!(w.rs == 1 && w.cs >= m)) {  // the kernels address reflector j as a contiguous column
+        Mat<T> wc = tmp_colmajor<T>(c, m, k);
+        copy_mat(c, w, wc);
+        w = wc;
+    }
+    if (q.rs == 1 && q.cs >= q.rows) {
+        form_q(c, w, ident, tau, k, q);
+    } else {
+        Mat<T> qw = tmp_colmajor<T>(c, m, k);
+        form_q(c, w, ident, tau, k, qw);
+        copy_mat(c, qw, q);
+    }
+}
+
 // ComputeSVD::compute_svd on a working matrix: wt is the TALL orientation
 // (M x r column-major, destroyed), i.e. a itself when m >= n, a^T otherwise.
 template <typename T>
@@ -1267,6 +1325,19 @@ rc_status rc_invert_permutation(rc_context *ctx, const int64_t *perm, int64_t n,
     }                                                                                                                                    \
     rc_status rc_pivoted_lq_##SUF(rc_context *ctx, rc_matrix a, rc_matrix l, rc_matrix q, int64_t *ind) {                                \
         return guarded(ctx, [&] { pivoted_qr<T>(ctx, from_c<T>(a).t(), from_c<T>(q).t(), from_c<T>(l).t(), ind); });                     \
+    }                                                                                                                                    \
+    rc_status rc_geqp3_##SUF(rc_context *ctx, rc_matrix a, int64_t kmax, int64_t *jpvt, T *tau) {                                        \
+        return guarded(ctx, [&] { lapack_geqp3<T>(ctx, from_c<T>(a), kmax, jpvt, tau); });                                               \
+    }                                                                                                                                    \
+    rc_status rc_orgqr_##SUF(rc_context *ctx, rc_matrix a, const T *tau, int64_t k, rc_matrix q) {                                       \
+        return guarded(ctx, [&] { lapack_orgqr<T>(ctx, from_c<T>(a), tau, k, from_c<T>(q)); });                                          \
+    }                                                                                                                                    \
+    rc_status rc_trsm_upper_##SUF(rc_context *ctx, rc_matrix t, rc_matrix b) {                                                           \
+        return guarded(ctx, [&] {                                                                                                        \
+            Mat<T> tt = from_c<T>(t), bb = from_c<T>(b);                                                                                 \
+            RC_REQUIRE(tt.rows == tt.cols && tt.rows == bb.rows, RC_INVALID_ARGUMENT, "trsm_upper: t must be k x k, b k x nrhs");       \
+            trsm_upper<T>(ctx, tt, bb);                                                                                                  \
+        });                                                                                                                              \
     }                                                                                                                                    \
     rc_status rc_compute_svd_##SUF(rc_context *ctx, rc_matrix a, rc_matrix u, T *s, rc_matrix vt) {                                      \
         return guarded(ctx, [&] { compute_svd<T>(ctx, from_c<T>(a), from_c<T>(u), s, from_c<T>(vt)); });                                 \

@@ -392,17 +392,21 @@ __global__ __launch_bounds__(256) void k_c_form_q(CV<R> w, const int64_t *jpvt, 
         const cplx<R> tj = tau[j];
         if (tj.re == (R)0 && tj.im == (R)0) continue;
         const cplx<R> *v = w.p + jpvt[j] * w.cs;
+        // thread tid owns the rows i = tid (mod 256) for the whole kernel: x[i] is only ever touched by its owner (the loops used
+        // to start at j + tid, which moved a row from thread to thread between steps with no barrier in between: a race between
+        // waves, visible as ~1e-4 errors of the c32 factor at k = 200)
+        const int64_t i0 = tid >= j ? tid : tid + ((j - tid + 255) / 256) * 256;
         cplx<R> dot{0, 0};
-        for (int64_t i = j + tid; i < m; i += 256) {
+        for (int64_t i = i0; i < m; i += 256) {
             const cplx<R> vi = i == j ? cplx<R>{(R)1, (R)0} : v[i];
-            dot = dot + cj(vi) * x[i];  // same thread wrote x[i]
+            dot = dot + cj(vi) * x[i];
         }
         R dr = wsumc(dot.re), di = wsumc(dot.im);
         __syncthreads();
         if (lane == 0) { sh[wv] = dr; sh[4 + wv] = di; }
         __syncthreads();
         const cplx<R> f = tj * cplx<R>{(sh[0] + sh[1]) + (sh[2] + sh[3]), (sh[4] + sh[5]) + (sh[6] + sh[7])};
-        for (int64_t i = j + tid; i < m; i += 256) {
+        for (int64_t i = i0; i < m; i += 256) {
             const cplx<R> vi = i == j ? cplx<R>{(R)1, (R)0} : v[i];
             x[i] = x[i] - f * vi;
         }
@@ -442,6 +446,37 @@ void c_pivoted_qr(rc_context *c, CV<R> a, CV<R> q, CV<R> r, int64_t *ind, int64_
         hipLaunchKernelGGL(k_c_form_q<R>, dim3((unsigned)q.cols), dim3(256), 0, c->stream, w, ind, tau, k, qw);
         c_copy(c, qw, q);
     }
+}
+
+// LAPACK granularity (see lapack_geqp3 / lapack_orgqr in rc_api.hip): ?geqp3 with the columns in pivoted order, ?ungqr
+template <typename R>
+void c_lapack_geqp3(rc_context *c, CV<R> a, int64_t kmax, int64_t *jpvt, cplx<R> *tau) {
+    const int64_t m = a.rows, n = a.cols;
+    RC_REQUIRE(kmax >= 0 && kmax <= std::min(m, n), RC_INVALID_ARGUMENT, "geqp3: need 0 <= kmax <= min(m, n)");
+    RC_REQUIRE(jpvt != nullptr && (kmax == 0 || tau != nullptr), RC_INVALID_ARGUMENT, "geqp3: null jpvt / tau");
+    if (n == 0) return;
+    if (kmax == 0 || m == 0) { iota_i64(c, jpvt, n); return; }
+    ArenaMark mark(c);
+    CV<R> w = tmp_cm<R>(c, m, n);
+    c_copy(c, a, w);
+    c_geqp3(c, w, kmax, jpvt, tau);
+    c_gather_cols(c, w, jpvt, a);
+}
+template <typename R>
+void c_lapack_ungqr(rc_context *c, CV<R> a, const cplx<R> *tau, int64_t k, CV<R> q) {
+    const int64_t m = a.rows;
+    RC_REQUIRE(k >= 0 && k <= std::min(m, a.cols) && q.rows == m && q.cols == k, RC_INVALID_ARGUMENT,
+               "orgqr: need k <= min(m, n) reflectors in a and q of m x k");
+    if (k == 0 || m == 0) return;
+    RC_REQUIRE(tau != nullptr, RC_INVALID_ARGUMENT, "orgqr: null tau");
+    ArenaMark mark(c);
+    int64_t *ident = c->alloc<int64_t>((size_t)k);
+    iota_i64(c, ident, k);
+    CV<R> w = tmp_cm<R>(c, m, k), qw = tmp_cm<R>(c, m, k);
+    CV<R> ak = a; ak.cols = k;
+    c_copy(c, ak, w);
+    hipLaunchKernelGGL(k_c_form_q<R>, dim3((unsigned)k), dim3(256), 0, c->stream, w, ident, tau, k, qw);
+    c_copy(c, qw, q);
 }
 
 // ------------------------------------------------------------------------------------------------ SVD (one-sided Jacobi)
@@ -1033,6 +1068,20 @@ extern "C" {
             CV<R> A = view_of<R>(a), Q = view_of<R>(q), Rr = view_of<R>(r);                                                               \
             RC_REQUIRE(Q.rows == A.rows && Rr.cols == A.cols && Rr.rows == Q.cols, RC_INVALID_ARGUMENT, "pivoted_qr: output shapes");     \
             c_pivoted_qr<R>(ctx, A, Q, Rr, ind, Q.cols);                                                                                  \
+        });                                                                                                                               \
+    }                                                                                                                                     \
+    rc_status rc_geqp3_##SUF(rc_context *ctx, rc_matrix a, int64_t kmax, int64_t *jpvt, CT *tau) {                                        \
+        return guarded_c(ctx, [&] { c_lapack_geqp3<R>(ctx, view_of<R>(a), kmax, jpvt, reinterpret_cast<cplx<R> *>(tau)); });             \
+    }                                                                                                                                     \
+    rc_status rc_orgqr_##SUF(rc_context *ctx, rc_matrix a, const CT *tau, int64_t k, rc_matrix q) {                                       \
+        return guarded_c(ctx, [&] { c_lapack_ungqr<R>(ctx, view_of<R>(a), reinterpret_cast<const cplx<R> *>(tau), k, view_of<R>(q)); }); \
+    }                                                                                                                                     \
+    rc_status rc_trsm_upper_##SUF(rc_context *ctx, rc_matrix t, rc_matrix b) {                                                            \
+        return guarded_c(ctx, [&] {                                                                                                       \
+            CV<R> tt = view_of<R>(t), bb = view_of<R>(b);                                                                                 \
+            RC_REQUIRE(tt.rows == tt.cols && tt.rows == bb.rows, RC_INVALID_ARGUMENT, "trsm_upper: t must be k x k, b k x nrhs");        \
+            if (bb.empty()) return;                                                                                                       \
+            hipLaunchKernelGGL(k_c_trsm_upper<R>, dim3((unsigned)cdivi(bb.cols, 256)), dim3(256), 0, ctx->stream, tt, bb);                \
         });                                                                                                                               \
     }                                                                                                                                     \
     rc_status rc_pivoted_lq_##SUF(rc_context *ctx, rc_matrix a, rc_matrix l, rc_matrix q, int64_t *ind) {                                 \

@@ -319,6 +319,42 @@ static void sharded_test(const Context &ctx) {
     });
 }
 
+// The LAPACK seam (rc_geqp3 / rc_orgqr / rc_trsm_upper where the reference calls $qrf, lax::Lapack::q and solve_triangular:
+// src/pivoted_qr.rs:139-172, :104-108, src/qr.rs:298): the two-call route must give the fused call's factorization.
+template <typename T>
+static void lapack_seam_tests(const Context &ctx, const std::string &suf, double tol) {
+    run_test("lapack_seam_geqp3_orgqr_equal_the_fused_pivoted_qr_" + suf, [&] {
+        const int64_t m = 150, n = 90, k = 90;
+        auto a = random_approximate_low_rank_matrix<T>(ctx, m, n, 1.0, 1e-3, seed_of("seam-" + suf));
+        auto fused = QR<T>::compute_from(a);
+        auto f = geqp3(a);
+        auto q = orgqr(f, k);
+        auto ji = f.jpvt.to_host(), fi = fused.ind.to_host();
+        int agree = 0;
+        while (agree < (int)k && ji[(size_t)agree] == fi[(size_t)agree]) ++agree;
+        CHECK(agree >= 20);   // the data-determined prefix (the tail of a 1e-3 spectrum ties in f32)
+        // R = upper triangle of the first k rows of the factored matrix (src/pivoted_qr.rs:100-102), compared on the agreed prefix
+        auto fa = f.a.to_host(), fr = fused.r.to_host(), qh = q.to_host(), fq = fused.q.to_host();
+        double num = 0, den = 0, qn = 0, qd = 0;
+        for (int64_t i = 0; i < agree; ++i)
+            for (int64_t j = i; j < agree; ++j) {
+                num += std::norm(fa[(size_t)(i * n + j)] - fr[(size_t)(i * n + j)]);
+                den += std::norm(fr[(size_t)(i * n + j)]);
+            }
+        for (int64_t i = 0; i < m; ++i)
+            for (int64_t j = 0; j < agree; ++j) {
+                qn += std::norm(qh[(size_t)(i * k + j)] - fq[(size_t)(i * k + j)]);
+                qd += std::norm(fq[(size_t)(i * k + j)]);
+            }
+        CHECK(std::sqrt(num / den) < tol && std::sqrt(qn / qd) < tol);
+        // T X = B
+        auto r11 = fused.r.leading(k, k);
+        auto b = random_gaussian<T>(ctx, k, 37, 5);
+        auto x = trsm_upper(r11, b);
+        CHECK((double)rel_diff_fro(dot(r11, x), b) < 1e3 * tol);   // forward residual through a triangle of condition ~1e3
+    });
+}
+
 // The range finders over an OPERATOR instead of a dense array (impl<Op: MatMat> SampleRange for Op, src/random_sampling.rs:102, :130, :222;
 // compute_from_range_estimate<Op: ConjMatMat>, src/qr.rs:311-323, src/svd.rs:171-183): the reference has no tests of these, the two below
 // pin the callback path of the C ABI (rc_operator) from compiled host code.
@@ -384,6 +420,8 @@ int main() {
     permutation_tests(ctx);
     sharded_test(ctx);
     operator_tests(ctx);
+    lapack_seam_tests<double>(ctx, "f64", 1e-10);
+    lapack_seam_tests<c32>(ctx, "c32", 1e-4);
     std::printf("%d tests, %d failed\n", tests_run, failures);
     return failures ? 1 : 0;
 }

@@ -1481,7 +1481,7 @@ def test_cpp_twin_of_the_rust_crate_passes_the_reference_unit_tests(tmp_path):
     res = subprocess.run([exe], capture_output=True, text=True, timeout=600)
     print(res.stdout[-4000:])
     assert res.returncode == 0, res.stdout[-6000:] + res.stderr
-    assert "93 tests, 0 failed" in res.stdout
+    assert "95 tests, 0 failed" in res.stdout
 
 
 _JACOBI_VARIANT_SNIPPET = r"""
