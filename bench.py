@@ -113,6 +113,7 @@ def parse_args(argv=None):
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-baseline-reps", type=int, default=2, help="compressions timed on the host (about 5 s each on the GPU box)")
     ap.add_argument("--no-concurrency-hint", action="store_true", help="leave RC_OPT_CONCURRENCY_HINT at 1 (every GEMM splits K for a lone launch)")
+    ap.add_argument("--no-gemm-lanes", action="store_true", help="skip roofline.in_flight_live (every lane running only the two big products, after the timed region)")
     ap.add_argument("--no-h2d", action="store_true", help="skip the second throughput figure that re-uploads A before every compression")
     ap.add_argument("--dry-run", action="store_true",
                     help="launcher / rendezvous rehearsal WITHOUT a GPU: ranks meet over gloo, run barriers and the MAX reduction around sleeps; "
@@ -450,6 +451,63 @@ def run_cfg3(args):
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
+    # ... and LIVE, un-traced: every lane runs ONLY the two big products of a compression (sketch, projection: the launches of the
+    # timed graphs, un-split) back to back for a few rounds -- the rate the products reach when the chip holds nothing else but
+    # products.  (A kernel trace serialises part of the concurrency, so the traced durations above are a LOWER bound of the
+    # in-flight cost: this figure is the one to price the pipeline's GEMM share with.)
+    in_flight_live = None
+    if rank == 0 and world == 1 and not args.no_gemm_lanes and S >= 8:
+        try:
+            fl_live, _ = work_model(m, n, k, p, with_id)
+            pl = []
+            for ln in lanes:
+                with torch.cuda.stream(ln["stream"]):
+                    om_ = rc.random_gaussian((n, l + (l & 1)), rc.Rng(3), dt)[:, :l]
+                    y_ = torch.empty((l, m), dtype=dt, device="cuda").t()
+                    b_ = torch.empty((k, n), dtype=dt, device="cuda")
+                pl.append((om_, y_, b_))
+
+            def products(ln, om_, y_, b_):
+                ln["ctx"].call("rc_matmat_f64", _lib.mat(ln["a"]), _lib.mat(om_), _lib.mat(y_))
+                ln["ctx"].call("rc_gemm_f64", ctypes.c_int32(1), ctypes.c_int32(0), ctypes.c_double(1.0), _lib.mat(ln["bufs"]["range_q"]), _lib.mat(ln["a"]),
+                               ctypes.c_double(0.0), _lib.mat(b_))
+            pgraphs = []
+            for ln, bufs_ in zip(lanes, pl):   # replayed as graphs like the timed region (same stream -> queue regime)
+                with torch.cuda.stream(ln["stream"]):
+                    g_ = ctypes.c_void_p(None)
+                    if ln["graph"]:
+                        products(ln, *bufs_)
+                        ln["ctx"].synchronize()
+                        ln["ctx"].check(_lib.lib().rc_graph_begin_capture(ln["ctx"]._h))
+                        products(ln, *bufs_)
+                        ln["ctx"].check(_lib.lib().rc_graph_end_capture(ln["ctx"]._h, ctypes.byref(g_)))
+                    pgraphs.append(g_)
+
+            def products_round():
+                for ln, bufs_, g_ in zip(lanes, pl, pgraphs):
+                    with torch.cuda.stream(ln["stream"]):
+                        if g_:
+                            ln["ctx"].check(_lib.lib().rc_graph_launch(ln["ctx"]._h, g_))
+                        else:
+                            products(ln, *bufs_)
+            products_round()
+            sync_all()
+            rounds = 8
+            tg0 = time.perf_counter()
+            for _ in range(rounds):
+                products_round()
+            sync_all()
+            tp = (time.perf_counter() - tg0) / (rounds * S)
+            gf = fl_live["sketch_gemm"] + fl_live["project_gemm"]
+            in_flight_live = {"what": "S lanes x (sketch + projection), un-split launches, nothing else on the chip, no trace", "lanes": S, "rounds": rounds,
+                              "ms_per_pair_chip_time": round(tp * 1e3, 4), "tflops": round(gf / tp / 1e12, 2), "frac": round(gf / tp / 1e12 / F64_MFMA_PEAK_TFLOPS, 4),
+                              "share_of_a_compression": round(tp / (elapsed / (args.steps * S)), 4)}
+            for ln, g_ in zip(lanes, pgraphs):
+                if g_:
+                    _lib.lib().rc_graph_destroy(ln["ctx"]._h, g_)
+            del pl
+        except Exception as e:  # a diagnostic: never fails the bench line
+            in_flight_live = {"error": repr(e)}
     # ---- second figure: every compression first re-uploads its A from pinned host memory on its own
     # lane (the reference's API takes host ndarrays); one round over all lanes, never `value` ------------------------
     h2d = None
@@ -590,7 +648,7 @@ def run_cfg3(args):
             except Exception:
                 in_flight = None
         roof = {"bound": "mfma", "kernel": "%s (sketch Y = A*Omega, %dx%dx%d, run as Y^T = Omega^T A^T)" % (sketch_kernel_name() or "k_gemm_f64", m, l, n), "achieved": round(achieved, 3),
-                "peak": F64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / F64_MFMA_PEAK_TFLOPS, 4), "traffic": traffic, "traffic_source": traffic_src, "in_flight": in_flight,
+                "peak": F64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / F64_MFMA_PEAK_TFLOPS, 4), "traffic": traffic, "traffic_source": traffic_src, "in_flight": in_flight, "in_flight_live": in_flight_live,
                 "avg_launch_ms": round(ms_launch, 4), "gemm_ms": round(ms_gemm, 4), "splitk_reduce_ms": round(ms_reduce, 4), "launches_timed": len(samples),
                 "launch_ms_samples_before_timed_region": [round(x[key], 4) for x in prof_before if key in x],
                 "launch_ms_samples_after_timed_region": [round(x[key], 4) for x in samples_after if key in x],

@@ -16,6 +16,7 @@ ap.add_argument("--rank", type=int, default=128)
 ap.add_argument("--oversample", type=int, default=5)
 ap.add_argument("--pad", type=int, default=0, help="lane s starts its matrix s*pad elements into its allocation (address alignment between lanes)")
 ap.add_argument("--stagger-us", type=int, default=0, help="host sleep between the first launches of the lanes")
+ap.add_argument("--graph", type=int, default=0, help="1: every lane replays a captured hipGraph of its two products (as bench.py does with the whole compression)")
 ap.add_argument("--hint", type=int, default=-1, help="RC_OPT_CONCURRENCY_HINT (default: the number of lanes)")
 args = ap.parse_args()
 m = n = args.size; k = args.rank; l = k + args.oversample; S = args.streams
@@ -43,6 +44,11 @@ for s in range(S):
             ctx.call("rc_matmat_f64", _lib.mat(a), _lib.mat(omega), _lib.mat(y))
             ctx.call("rc_gemm_f64", ctypes.c_int32(1), ctypes.c_int32(0), ctypes.c_double(1.0), _lib.mat(q), _lib.mat(a), ctypes.c_double(0.0), _lib.mat(b))
         call(); ctx.synchronize()
+        if args.graph:
+            g = ctypes.c_void_p(None)
+            ctx.check(lib.rc_graph_begin_capture(ctx._h)); call(); ctx.check(lib.rc_graph_end_capture(ctx._h, ctypes.byref(g)))
+            call = (lambda ctx=ctx, g=g: ctx.check(lib.rc_graph_launch(ctx._h, g)))
+            call(); ctx.synchronize()
         lanes.append((st, ctx, call, a, omega, y, q, b))
 names = set()
 for r in range(2):
@@ -57,4 +63,4 @@ torch.cuda.synchronize()
 t = time.perf_counter() - t0
 per = t / (args.rounds * S)
 flops = 2.0 * m * n * (l + k)
-print(f"pad={args.pad} lanes={S} pairs/s={1/per:.1f} ms_per_pair={per*1e3:.4f} TFLOP/s={flops/per/1e12:.2f} frac_of_78.6={flops/per/78.6e12:.3f}")
+print(f"graph={args.graph} hwq={os.environ.get('GPU_MAX_HW_QUEUES')} pad={args.pad} lanes={S} pairs/s={1/per:.1f} ms_per_pair={per*1e3:.4f} TFLOP/s={flops/per/1e12:.2f} frac_of_78.6={flops/per/78.6e12:.3f}")
