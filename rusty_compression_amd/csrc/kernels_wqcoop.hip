@@ -182,11 +182,12 @@ __global__ __launch_bounds__(512, NE <= 4 ? 4 : 2) void k_wq_coop(WqCoopArgs<T> 
         const int cl = g8 + NG * q;
         const bool valid = cl < nloc;
         const T *col = src.p + (int64_t)(c0 + (valid ? cl : 0)) * src.cs;
+        const int64_t srs = src.rs;  // 1 for wf; the INPUT may have any strides (the row-major B = Q^H A is read where it lies)
         T ss = 0;
 #pragma unroll
         for (int e = 0; e < NE; ++e) {
             const int i = row0 + l8 + 8 * e;
-            x[q][e] = (valid && i < m) ? col[i] : (T)0;
+            x[q][e] = (valid && i < m) ? col[(int64_t)i * srs] : (T)0;
             ss = fma(x[q][e], x[q][e], ss);
         }
         ss = group_sum_dpp<8>(ss);
@@ -621,7 +622,7 @@ bool wide_coop_supported(int64_t m, int64_t n, int device) {
 // test_wide_qrcp_paths_match_lapack_and_each_other compares them).
 template <typename T>
 void geqp3_wide_coop(rc_context *c, Mat<T> w, Mat<T> wf, int64_t kmax, int64_t *jpvt, T *tau, int *flag) {
-    RC_REQUIRE(w.rs == 1 && wf.rs == 1 && wf.rows == w.rows && wf.cols == w.cols, RC_LAYOUT_ERROR, "geqp3_wide_coop: column-major operands required");
+    RC_REQUIRE(wf.rs == 1 && wf.rows == w.rows && wf.cols == w.cols, RC_LAYOUT_ERROR, "geqp3_wide_coop: column-major output required");  // w: any strides, read once, never written
     const int64_t m = w.rows, n = w.cols;
     kmax = std::min(kmax, std::min(m, n));
     RC_REQUIRE(wide_coop_supported<T>(m, n, c->device), RC_INVALID_ARGUMENT, "geqp3_wide_coop: unsupported shape");

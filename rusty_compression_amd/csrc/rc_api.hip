@@ -312,12 +312,22 @@ bool run_certified(rc_context *c, F &&fast) {
 //   q: m x k (may be empty to skip), r: k x n (may be empty), ind: n, k <= min(m, n)
 // Tall-skinny inputs take the CholeskyQR2 + LDS-QRCP + sign-fix path (kernels_tsqr.hip) and
 // fall back to the Householder chain when its certificate fails (cond(w)^2 eps not << 1).
+// keep_w: w (any layout) must survive -- the tall-skinny path and the cooperative short-wide kernel only READ their input, so
+// they run on it where it lies; every other path gets a column-major working copy first (B = Q^H A is shared by the two
+// consumers of rc_rsvd_id: the copy, one pass over B per compression, is only taken when a fallback needs it).
 template <typename T>
-void qrcp_core(rc_context *c, Mat<T> w, int64_t k, bool pivot, Mat<T> q, Mat<T> r, int64_t *ind) {
+void qrcp_core(rc_context *c, Mat<T> w, int64_t k, bool pivot, Mat<T> q, Mat<T> r, int64_t *ind, bool keep_w = false) {
     const int64_t n = w.cols;
     ArenaMark mark(c);
     if (c->opt_tsqr && k >= 1 && tsqr_supported<T>(w.rows, n)) {
         if (run_certified(c, [&](int *flag) { qrcp_tall_fast<T>(c, w, k, pivot, q, r, ind, flag); })) return;
+    }
+    static const int direct_ok = [] { const char *e = getenv("RC_QRCP_KEEP_DIRECT"); return e ? atoi(e) : 1; }();
+    if (keep_w && !(direct_ok && c->opt_wide_coop && pivot && k >= 1 && wide_coop_supported<T>(w.rows, n, c->device))) {
+        Mat<T> cp = tmp_colmajor<T>(c, w.rows, n);
+        copy_mat(c, w, cp);
+        w = cp;
+        keep_w = false;
     }
     if (c->opt_wide_coop && pivot && k >= 1 && wide_coop_supported<T>(w.rows, n, c->device)) {
         T *tau = c->alloc<T>((size_t)k);
@@ -335,6 +345,11 @@ void qrcp_core(rc_context *c, Mat<T> w, int64_t k, bool pivot, Mat<T> q, Mat<T> 
             }
             return;
         }
+    }
+    if (keep_w) {  // the cooperative kernel did not certify (eager mode: fall back on a copy)
+        Mat<T> cp = tmp_colmajor<T>(c, w.rows, n);
+        copy_mat(c, w, cp);
+        w = cp;
     }
     if (c->opt_wide_lazy && pivot && k >= 1 && wide_lazy_supported<T>(w.rows, n)) {
         geqp3_wide_lazy<T>(c, w, k, ind, q, r);
@@ -851,21 +866,24 @@ template <typename T>
 void rsvd_id_consumers(rc_context *c, Mat<T> range, Mat<T> b, const rc_rsvd_id_out &o) {
     const int64_t m = range.rows, k = b.rows, n = b.cols;
     const bool want_id = o.id_c.data || o.id_z.data || o.qr_q.data || o.qr_r.data || o.qr_ind;
+    const bool want_svd = o.u.data || o.s || o.vt.data;
+    if (want_svd) RC_REQUIRE(o.u.data && o.s && o.vt.data, RC_INVALID_ARGUMENT, "rsvd_id: u, s, vt must be given together");
+    // the two consumers of B are independent: the ID branch goes to the side stream, the SVD branch stays here.  Side by side
+    // (RC_OPT_FORK_BRANCHES) the ID branch works on its own copy of B, taken before the fork (the SVD branch may overwrite B);
+    // one after the other the pivoted QR reads B where it lies
     Mat<T> wq;
-    if (want_id) {
+    if (want_id && want_svd && c->opt_fork) {
         wq = tmp_colmajor<T>(c, k, n);
         copy_mat(c, b, wq);
     }
-    const bool want_svd = o.u.data || o.s || o.vt.data;
-    if (want_svd) RC_REQUIRE(o.u.data && o.s && o.vt.data, RC_INVALID_ARGUMENT, "rsvd_id: u, s, vt must be given together");
-    // the two consumers of B are independent: the ID branch goes to the side stream, the SVD branch stays here
     Fork fork(c, want_svd && want_id);
     if (want_id) {
         ProfScope ps(c, "stage:qrcp of B + column_id");
         Mat<T> qb = tmp_colmajor<T>(c, k, k);
         Mat<T> r = o.qr_r.data ? from_c<T>(o.qr_r) : tmp_rowmajor<T>(c, k, n);
         int64_t *ind = o.qr_ind ? o.qr_ind : c->alloc<int64_t>((size_t)n);
-        qrcp_core(c, wq, k, true, qb, r, ind);
+        if (wq.p) qrcp_core(c, wq, k, true, qb, r, ind);
+        else qrcp_core(c, b, k, true, qb, r, ind, /*keep_w=*/want_svd);   // the SVD consumer below still needs B
         Mat<T> q = o.qr_q.data ? from_c<T>(o.qr_q) : tmp_colmajor<T>(c, m, k);
         gemm<T>(c, 1, range, qb, 0, q);
         if (o.id_c.data || o.id_z.data) {
