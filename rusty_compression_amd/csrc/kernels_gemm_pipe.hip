@@ -794,7 +794,7 @@ static bool launch_r(rc_context *c, const GemmArgs<double> &g) {
         attr_set[c->device & 63] = true;
     }
     char nm[128];
-    snprintf(nm, sizeof(nm), "k_gemm_f64r<%d,%d,%d,%d,%d,%d,%s>", BLAY, ORIENT, BM, BN, WM, WN, MASKTAIL ? "true" : "false");
+    snprintf(nm, sizeof(nm), "k_gemm_f64r<%d,%d,%d,%d,%d,%d,%s,%d>", BLAY, ORIENT, BM, BN, WM, WN, MASKTAIL ? "true" : "false", DBG);  // as rocprofv3 prints it
     c->last_gemm_kernel = nm;
     ProfScope ps(c, "kernel:k_gemm_mfma<f64> M=%lld N=%lld K=%lld", (long long)g.M, (long long)g.N, (long long)g.K);
     hipLaunchKernelGGL(kern, dim3((unsigned)(g.tiles_m * g.tiles_n), (unsigned)g.splits), dim3(NT), lds, c->stream, g);

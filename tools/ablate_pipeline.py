@@ -45,6 +45,12 @@ def make_call(mode, ctx, a, b, seed):
             ctx.call("rc_sample_range_by_rank_f64", _lib.mat(a), ctypes.c_int64(k), ctypes.c_int64(p), _lib.mat(None), ctypes.c_uint64(seed), _lib.mat(b["range_q"]))
             ctx.call("rc_gemm_f64", ctypes.c_int32(1), ctypes.c_int32(0), ctypes.c_double(1.0), _lib.mat(b["range_q"]), _lib.mat(a), ctypes.c_double(0.0), _lib.mat(b["bb"]))
         return call
+    if mode == "geqp3":   # range + the pivoted QR kernel of B alone (rc_geqp3: copy, cooperative kernel, gather)
+        def call():
+            ctx.call("rc_sample_range_by_rank_f64", _lib.mat(a), ctypes.c_int64(k), ctypes.c_int64(p), _lib.mat(None), ctypes.c_uint64(seed), _lib.mat(b["range_q"]))
+            ctx.call("rc_gemm_f64", ctypes.c_int32(1), ctypes.c_int32(0), ctypes.c_double(1.0), _lib.mat(b["range_q"]), _lib.mat(a), ctypes.c_double(0.0), _lib.mat(b["bb"]))
+            ctx.call("rc_geqp3_f64", _lib.mat(b["bb"]), ctypes.c_int64(k), _lib.i64p(b["qr_ind"]), ctypes.c_void_p(b["s"].data_ptr()))
+        return call
     svd = mode in ("svd", "full"); idb = mode in ("id", "full"); qrb = idb or mode == "qr"   # qr: QR::compute_from_range_estimate without the ID
     out = _lib.rc_rsvd_id_out(_lib.mat(b["range_q"]), _lib.mat(b["u"]) if svd else none, ctypes.c_void_p(b["s"].data_ptr() if svd else None), _lib.mat(b["vt"]) if svd else none,
                               _lib.mat(b["qr_q"]) if qrb else none, _lib.mat(b["qr_r"]) if qrb else none, ctypes.c_void_p(b["qr_ind"].data_ptr() if qrb else None),

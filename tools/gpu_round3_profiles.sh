@@ -3,7 +3,7 @@
 # into profiles/.  EVERY step's failure ends the script with a non-zero status (a failing step was reported as rc=0).
 #   1. driver-style bench line
 #   2. rocprofv3 kernel-trace stats of the bench with ONE stream (uncontended durations of the final kernels) + timeline
-#   3. the same at the default 42 lanes (in-flight durations: the un-split GEMM launches the timed region runs) + timeline + in_flight.json
+#   3. the same at the default 40 lanes (in-flight durations: the un-split GEMM launches the timed region runs) + timeline + in_flight.json
 #   4. PMC passes on the two big products, lone launches (FETCH_SIZE; WRITE_SIZE; MFMA busy + clock), one group per pass
 #   5. cfg5: kernel trace + FETCH_SIZE / WRITE_SIZE of rank-64 column IDs; cfg5 / cfg4 timings (tools/qrblk_bench.py); cfg5 bench line
 set -o pipefail
@@ -16,20 +16,20 @@ die() { echo "FAILED: $1" | tee -a $O/progress.log; exit 1; }
 step() { echo "== $1 $(date +%T)" | tee -a $O/progress.log; }
 step "bench driver-style"
 timeout -k 10 400 python bench.py --steps 20 --warmup 5 > $O/bench_driver.json 2> $O/bench_driver.err || die "bench"
-for S in 1 42; do
+for S in 1 40; do
   step "rocprof kernel trace, $S stream(s)"
-  ( cd /tmp && timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_s$S -- python3 $R/bench.py --streams $S --steps 16 --warmup 4 --no-cpu-baseline --no-h2d > $O/rocprof_s$S.log 2>&1 ) || die "rocprof streams=$S"
+  ( cd /tmp && timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_s$S -- python3 $R/bench.py --streams $S --steps 16 --warmup 4 --no-cpu-baseline --no-h2d --no-gemm-lanes > $O/rocprof_s$S.log 2>&1 ) || die "rocprof streams=$S"
   f=$(ls -t $O/prof_s$S/*/*kernel_trace.csv | head -1)
   python tools/timeline.py $f --frac 0.4 --top 45 > $O/timeline_s$S.txt || die "timeline $S"
   cp $(ls -t $O/prof_s$S/*/*kernel_stats.csv | head -1) $O/kernel_stats_s$S.csv
-  if [ $S = 42 ]; then cp $f $O/kernel_trace_s42.csv; fi
+  if [ $S = 40 ]; then cp $f $O/kernel_trace_s40.csv; fi
   rm -rf $O/prof_s$S
 done
 python - <<'PY' || exit 1
-# in-flight record of the two big products: launches of the un-split grid (32 workgroups) in the 42-lane trace
+# in-flight record of the two big products: launches of the un-split grid (32 workgroups) in the 40-lane trace
 import csv, json, collections, re
 O = 'gpurun_out/r03p'
-rows = [r for r in csv.DictReader(open(O + '/kernel_trace_s42.csv')) if 'k_gemm_f64' in r['Kernel_Name']]
+rows = [r for r in csv.DictReader(open(O + '/kernel_trace_s40.csv')) if 'k_gemm_f64' in r['Kernel_Name']]
 t0, t1 = min(int(r['Start_Timestamp']) for r in rows), max(int(r['End_Timestamp']) for r in rows)
 lo = t1 - 0.4 * (t1 - t0)
 agg = collections.defaultdict(list)
@@ -43,12 +43,19 @@ out = {}
 for (name, wgs), v in agg.items():
     avg = sum(v) / len(v)
     out.setdefault(name.replace(' ', ''), []).append({"workgroups": wgs, "launches": len(v), "avg_us": round(avg, 2), "cu_time_us": round(avg * min(wgs, 256) / 256.0, 2)})
-json.dump({"source": "rocprofv3 --kernel-trace of `bench.py --streams 42 --steps 16 --warmup 4` (last 40 % of the trace), tools/gpu_round3_profiles.sh; "
+json.dump({"source": "rocprofv3 --kernel-trace of `bench.py --streams 40 --steps 16 --warmup 4` (last 40 % of the trace), tools/gpu_round3_profiles.sh; "
                      "cu_time_us = average duration x min(workgroups, 256) / 256; NOTE: tracing serialises part of the concurrency, durations are upper bounds",
            "kernels": out}, open(O + '/in_flight.json', 'w'), indent=1)
 print(json.dumps(out, indent=1))
 PY
-rm -f $O/kernel_trace_s42.csv
+rm -f $O/kernel_trace_s40.csv
+step "un-traced ablation of the pipeline + lane sweep"
+timeout -k 10 300 python tools/ablate_pipeline.py > $O/ablation.txt 2> $O/ablation.err || die "ablation"
+cat $O/ablation.txt
+for s in 24 32 40 44 48 64 68; do
+  timeout -k 10 200 python bench.py --streams $s --steps 16 --warmup 4 --no-cpu-baseline --no-h2d --no-gemm-lanes 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('lanes $s (24 hardware queues):', d['value'], 'compressions/s')" >> $O/lane_sweep.txt || die "lane sweep $s"
+done
+cat $O/lane_sweep.txt
 step "PMC passes on the big products (lone launches)"
 for grp in "FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE"; do
   tag=$(echo $grp | tr ' ' '_' | cut -c1-40)
@@ -120,6 +127,6 @@ print(json.dumps(per))
 PY
 rm -rf $O/pmc_gemm $O/pmc_cfg5 $O/prof_cfg5
 python -c "
-import json; d=json.load(open('$O/bench_driver.json')); print('driver-style:', d['value'], 'c/s', d['ms_per_step'], 'ms/step', d['frac_of_f64_mfma_peak_whole_pipeline'], d['roofline']['achieved'], d['roofline']['frac'], d['cpu_baseline']['value'], d['value_including_h2d']['value_including_h2d'])"
+import json; d=json.load(open('$O/bench_driver.json')); print('driver-style:', d['value'], 'c/s', d['ms_per_step'], 'ms/step', d['frac_of_f64_mfma_peak_whole_pipeline'], d['roofline']['achieved'], d['roofline']['frac'], d['cpu_baseline']['value'], d['value_including_h2d']['value_including_h2d'], d['roofline']['in_flight_live'])"
 cat $O/qrblk_bench.json | head -12
 step done
