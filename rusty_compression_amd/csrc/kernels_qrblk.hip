@@ -575,7 +575,8 @@ __global__ __launch_bounds__(256) void k_qrb_scatter(Mat<T> w, int j0, int kb, Q
 
 // Vp(i, t) = v_t(j0 + i): zeros above the diagonal, one on it, the reflector below  (rows x kb, column-major)
 template <typename T>
-__global__ __launch_bounds__(256) void k_qrb_build_vp(Mat<T> w, int j0, const QrbState *st, Mat<T> vp) {
+__global__ __launch_bounds__(256) void k_qrb_build_vp(Mat<T> w, int j0, const QrbState *st, Mat<T> vp, const int *ok) {
+    if (ok && *ok == 0) return;  // optimistic issue: an earlier panel broke an assumption, nothing behind it may run on its state
     const int t = blockIdx.y;
     const T *col = w.p + (int64_t)st->piv[t] * w.cs + j0;
     T *out = vp.p + (int64_t)t * vp.cs;
@@ -599,7 +600,8 @@ __global__ __launch_bounds__(256) void k_qrb_build_vp_pos(Mat<T> w, int j0, cons
 // ---------------------------------------------------------------------------
 template <typename T>
 __global__ __launch_bounds__(256) void k_qrb_finish(Mat<T> w, int j0, int kb, const int *pos, const unsigned char *is_cand, T *vn1, const T *vn2, T *Fm,
-                                                    const T *Y, int64_t ldy, const T *Tm, Mat<T> vp, int *flag, int coop, int nsplit, int64_t sstride) {
+                                                    const T *Y, int64_t ldy, const T *Tm, Mat<T> vp, int *flag, int coop, int nsplit, int64_t sstride, const int *ok) {
+    if (ok && *ok == 0) return;  // optimistic issue: an earlier panel broke an assumption, nothing behind it may run on its state
     __shared__ T Tl[kNB * kNB], Vl[kNB * kNB];
     for (int e = threadIdx.x; e < kNB * kNB; e += 256) {
         const int r = e % kNB, q = e / kNB;  // element (r, q)
@@ -680,7 +682,8 @@ __global__ __launch_bounds__(256) void k_qrb_finish(Mat<T> w, int j0, int kb, co
 // ---------------------------------------------------------------------------------------------------------------------
 typedef float vta_f4 __attribute__((ext_vector_type(4)));
 __global__ __launch_bounds__(256) void k_qrb_vta(const float *v, int64_t ldv, const float *a, int64_t lda, int rows, int n, int kb, float *ypart, int64_t ldy,
-                                                 int64_t sstride, int rows_per_split) {
+                                                 int64_t sstride, int rows_per_split, const int *ok) {
+    if (ok && *ok == 0) return;  // optimistic issue: an earlier panel broke an assumption, nothing behind it may run on its state
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int cl = lane & 15, g = lane >> 4;
     const int c0 = (blockIdx.x * 4 + wave) * 64;
@@ -761,7 +764,8 @@ __global__ __launch_bounds__(256) void k_qrb_vta(const float *v, int64_t ldv, co
 }
 // y[k][c] = sum over the slabs, in slab order (deterministic); slab 0 receives the sum.  (Folding this sum into k_qrb_finish was
 // measured: its 16 workgroups then issue 512 loads per thread and the panel end got 0.2 ms SLOWER.)
-__global__ __launch_bounds__(256) void k_qrb_ysum(float *ypart, int64_t ldy, int64_t sstride, int kb, int n, int nsplit) {
+__global__ __launch_bounds__(256) void k_qrb_ysum(float *ypart, int64_t ldy, int64_t sstride, int kb, int n, int nsplit, const int *ok) {
+    if (ok && *ok == 0) return;  // optimistic issue: an earlier panel broke an assumption, nothing behind it may run on its state
     const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (e >= (int64_t)kb * n) return;
     const int k = (int)(e / n), c = (int)(e % n);
@@ -771,10 +775,10 @@ __global__ __launch_bounds__(256) void k_qrb_ysum(float *ypart, int64_t ldy, int
     p[0] = acc;
 }
 template <typename T>
-static bool qrb_vta_launch(rc_context *, Mat<T>, Mat<T>, int, T *, int64_t, int64_t, int *) { return false; }
+static bool qrb_vta_launch(rc_context *, Mat<T>, Mat<T>, int, T *, int64_t, int64_t, int *, const int *) { return false; }
 // returns true and sets *nsplit when the streaming kernel ran (ypart: nsplit slabs of kNB x ldy); false: take the GEMM
 template <>
-bool qrb_vta_launch<float>(rc_context *c, Mat<float> vpp, Mat<float> wsub, int kb, float *ypart, int64_t ldy, int64_t sstride, int *nsplit) {
+bool qrb_vta_launch<float>(rc_context *c, Mat<float> vpp, Mat<float> wsub, int kb, float *ypart, int64_t ldy, int64_t sstride, int *nsplit, const int *ok) {
     static const int on = [] { const char *e = getenv("RC_QRCP_VTA"); return e ? atoi(e) : 1; }();
     const int64_t rows = wsub.rows, n = wsub.cols;
     if (!on || wsub.rs != 1 || vpp.rs != 1 || rows < 256 || n < 64 || kb > kNB) return false;
@@ -786,8 +790,8 @@ bool qrb_vta_launch<float>(rc_context *c, Mat<float> vpp, Mat<float> wsub, int k
     splits = (int)cdivb(rows, rps);
     ProfScope ps(c, "kernel:k_qrb_vta rows=%lld n=%lld kb=%d splits=%d", (long long)rows, (long long)n, kb, splits);
     hipLaunchKernelGGL(k_qrb_vta, dim3((unsigned)col_wgs, (unsigned)splits), dim3(256), 0, c->stream, vpp.p, vpp.cs, wsub.p, wsub.cs, (int)rows, (int)n, kb, ypart, ldy, sstride,
-                       (int)rps);
-    if (splits > 1) hipLaunchKernelGGL(k_qrb_ysum, dim3((unsigned)cdivb((int64_t)kb * n, 256)), dim3(256), 0, c->stream, ypart, ldy, sstride, kb, (int)n, splits);
+                       (int)rps, ok);
+    if (splits > 1) hipLaunchKernelGGL(k_qrb_ysum, dim3((unsigned)cdivb((int64_t)kb * n, 256)), dim3(256), 0, c->stream, ypart, ldy, sstride, kb, (int)n, splits, ok);
     *nsplit = 1;  // slab 0 holds Y
     return true;
 }
@@ -795,8 +799,10 @@ bool qrb_vta_launch<float>(rc_context *c, Mat<float> vpp, Mat<float> wsub, int k
 // exact norms of the flagged columns below row `row0` (?laqps: VN1 = VN2 = ?nrm2 after the block update)
 // all != 0: every unpivoted column (see qrb_finish)
 template <typename T>
-__global__ __launch_bounds__(256) void k_qrb_renorm(Mat<T> w, int row0, int all, const int *pos, int *flag, T *vn1, T *vn2) {
+__global__ __launch_bounds__(256) void k_qrb_renorm(Mat<T> w, int row0, int all, const int *pos, int *flag, T *vn1, T *vn2, const QrbState *st, const int *ok) {
+    if (ok && *ok == 0) return;  // optimistic issue: an earlier panel broke an assumption, nothing behind it may run on its state
     const int lane = threadIdx.x & 63;
+    if (st) all = st->lsticc;  // optimistic issue: the host has not seen the panel's state (same value, read where it lives)
     for (int64_t c = blockIdx.x * 4 + (threadIdx.x >> 6); c < w.cols; c += (int64_t)gridDim.x * 4) {
         if (!flag[c] && !all) continue;
         T acc = 0;
@@ -1284,7 +1290,8 @@ __global__ __launch_bounds__(512, WPE) void k_qrb_coop(QrbCoopArgs<T> a) {
 
 // T factor of a cooperative panel from the recorded v_t^T v_k (?larft, forward / columnwise): T(0:k, k) = -tau_k T(0:k, 0:k) d(0:k, k)
 template <typename T>
-__global__ __launch_bounds__(1024) void k_qrb_build_t(const T *D, const T *tau, int j0, int kb, T *Tm) {
+__global__ __launch_bounds__(1024) void k_qrb_build_t(const T *D, const T *tau, int j0, int kb, T *Tm, const int *ok) {
+    if (ok && *ok == 0) return;  // optimistic issue: an earlier panel broke an assumption, nothing behind it may run on its state
     // thread (i, t) = (tid / 32, tid % 32): the 32 products of row i with d(:, k), summed over the 32 lanes of a half wave
     __shared__ T Tl[kNB * kNB], Dl[kNB * kNB], taul[kNB];
     static_assert(kNB == 32, "one half wave per row of T");
@@ -1317,7 +1324,8 @@ __global__ __launch_bounds__(1024) void k_qrb_build_t(const T *D, const T *tau, 
 // ---------------------------------------------------------------------------------------------------------------------
 template <typename T, int RPT>
 __global__ __launch_bounds__(256) void k_qrb_block_update(Mat<T> w, int row0, int kb, int j0, Mat<T> vp, int vrow0, const T *Fm, const int *pos,
-                                                          const unsigned char *is_cand, int coop, int cols_per_wg) {
+                                                          const unsigned char *is_cand, int coop, int cols_per_wg, const int *proceed) {
+    if (proceed && *proceed == 0) return;  // optimistic issue: an earlier panel broke an assumption, nothing behind it may run on its state
     const int tid = threadIdx.x;
     const int64_t rows = w.rows - row0;
     const int64_t rbase = (int64_t)blockIdx.x * 256 * RPT;
@@ -1398,7 +1406,7 @@ static unsigned coop_units_per_wg(K kern) {
 }
 
 template <typename T>
-static bool qrb_coop_launch(rc_context *c, QrbCoopArgs<T> a, int g, int rows) {
+static bool qrb_coop_launch(rc_context *c, QrbCoopArgs<T> a, int g, int rows, const int *proceed) {
     constexpr int NE_BIG = coop_ne_big<T>(), NE_SMALL = NE_BIG / 4;
     const bool small = rows <= 64 * (16 / (int)sizeof(T)) * NE_SMALL;
     // f64 with 96 doubles of column per lane needs the whole register file of a SIMD for two waves; everything else leaves room
@@ -1407,7 +1415,7 @@ static bool qrb_coop_launch(rc_context *c, QrbCoopArgs<T> a, int g, int rows) {
     static const unsigned units_big = coop_units_per_wg(k_qrb_coop<T, NE_BIG, WPE_BIG>), units_small = coop_units_per_wg(k_qrb_coop<T, NE_SMALL, 4>);
     a.need = (unsigned)g * (small ? units_small : units_big);
     if (a.need > coop_budget_units(c->device)) return false;  // (a device with few CUs: the step kernels run instead)
-    coop_gate_launch(c, a.need, a.sync, a.hdr, 2 * g * 5);
+    coop_gate_launch(c, a.need, a.sync, a.hdr, 2 * g * 5, proceed);
     if (small) hipLaunchKernelGGL((k_qrb_coop<T, NE_SMALL, 4>), dim3((unsigned)g), dim3(512), 0, c->stream, a);
     else hipLaunchKernelGGL((k_qrb_coop<T, NE_BIG, WPE_BIG>), dim3((unsigned)g), dim3(512), 0, c->stream, a);
     return true;
@@ -1442,6 +1450,11 @@ struct BlockedQrcpJob {
     int coop_fallbacks = 0;
     int64_t cw_issued = 0;
     unsigned grid_a = 0, grid_c = 0;
+    // optimistic issue (qrb_issue_all_optimistic): panel p's state goes to host_st[log_base + p]; nbp_log[p] = the steps it was assumed to make
+    bool optimistic = false, opt_broken = false;
+    int *opt_ok = nullptr;  // device word: 1 while every assumption of the optimistic issue has held (k_qrb_opt_check clears it)
+    int log_base = 0, log_n = 0;
+    std::vector<int> nbp_log;
 };
 
 template <typename T>
@@ -1473,6 +1486,7 @@ BlockedQrcpJob<T> *qrb_begin(rc_context *c, Mat<T> w, int64_t kmax, int64_t *jpv
     P.flag = J->flag; P.tsc = J->tsc; P.tau = tau; P.Tm = J->Tm;
     J->st = reinterpret_cast<QrbState *>(c->alloc_bytes(sizeof(QrbState)));
     P.st = J->st;
+    J->opt_ok = c->alloc<int>(2);
     J->vp = colmajor(c->alloc<T>((size_t)even_ld(m) * kNB), m, kNB, even_ld(m));
     J->ldy = even_ld(n);
     J->Y = c->alloc<T>((size_t)kQrbVtaMaxSplits * kNB * J->ldy);  // up to kQrbVtaMaxSplits partial slabs of kNB x ldy (k_qrb_vta); slab 0 alone for the GEMM path
@@ -1487,8 +1501,13 @@ BlockedQrcpJob<T> *qrb_begin(rc_context *c, Mat<T> w, int64_t kmax, int64_t *jpv
     fill_words(c, J->Fm, ((size_t)n * kNB + (size_t)kNB * kNB) * sizeof(T), 0u);
     J->vec_ok = (w.cs % (16 / (int64_t)sizeof(T)) == 0 && reinterpret_cast<uintptr_t>(w.p) % 16 == 0) ? 1 : 0;
     hipLaunchKernelGGL(k_qrb_init<T>, dim3((unsigned)std::min<int64_t>(cdivb(n, 4), 8192)), dim3(256), 0, c->stream, w, jpvt, J->pos, J->vn1, J->vn2, J->flag);
-    // candidate budget: about RC_QRCP_CAND_MB of column data (L2-resident across the steps of a panel), at least 4 NB columns
-    static const int cand_mb = env_int_b("RC_QRCP_CAND_MB", 8);
+    // candidate budget: about RC_QRCP_CAND_MB of column data, at least 4 NB columns.  A cooperative panel holds one wave per candidate,
+    // so the budget is also its CU demand: 4 MB = 256 candidates = 32 workgroups for 4096 rows of f32 (8 MB until round 3: 64 workgroups;
+    // eight lanes' panels did not fit the device budget at once).  Fewer candidates end a panel earlier on flat norm profiles (the tau
+    // test; the next panel then asks for more).  Measured, 8 x 4096^2 f32 Gaussian, k = 64, batch of 8: 2450 (8 MB) -> 2690 (5) -> 2820 (4)
+    // -> 2940 (3) matrices/s, 1470 at 2 MB (every panel ends early); one matrix 0.91 -> 0.88 ms.  NOTE: R12 / Z differ in the last bits
+    // with the candidate count (candidates are updated reflector by reflector, the other columns through the block update).
+    static const int cand_mb = env_int_b("RC_QRCP_CAND_MB", 4);
     J->cwant = std::max<int64_t>(4 * kNB, ((int64_t)cand_mb << 20) / (int64_t)(sizeof(T) * (size_t)std::max<int64_t>(m, 1)));
     if (cand_mb <= 0) J->cwant = n;  // plain ?laqps
     // cooperative panels: header / candidate slots of up to kCoopWgs workgroups, the recorded v_t^T v_k
@@ -1519,7 +1538,7 @@ static void qrb_issue_launches(BlockedQrcpJob<T> *J, int nbp, int64_t cw, unsign
         hipLaunchKernelGGL(k_qrb_step_a<T>, dim3(grid_a), dim3(256), 0, c->stream, J->w, (int)j0, k, J->P);
         hipLaunchKernelGGL(k_qrb_step_c<T>, dim3(grid_c), dim3(256), 0, c->stream, J->w, (int)j0, k, (int)grid_a, J->vec_ok, J->P);
     }
-    RC_HIP(hipMemcpyAsync(J->host_st, J->st, sizeof(QrbState), hipMemcpyDeviceToHost, c->stream));
+    RC_HIP(hipMemcpyAsync(J->host_st + (J->optimistic ? J->log_base + J->log_n : 0), J->st, sizeof(QrbState), hipMemcpyDeviceToHost, c->stream));
 }
 
 template <typename T>
@@ -1545,8 +1564,8 @@ void qrb_issue(BlockedQrcpJob<T> *J) {
         QrbCoopArgs<T> a = J->coop;
         a.j0 = (int)j0;
         a.nbp = nbp;
-        if (qrb_coop_launch<T>(c, a, g, (int)(m - j0))) {
-            RC_HIP(hipMemcpyAsync(J->host_st, J->st, sizeof(QrbState), hipMemcpyDeviceToHost, c->stream));
+        if (qrb_coop_launch<T>(c, a, g, (int)(m - j0), J->optimistic ? J->opt_ok : nullptr)) {
+            RC_HIP(hipMemcpyAsync(J->host_st + (J->optimistic ? J->log_base + J->log_n : 0), J->st, sizeof(QrbState), hipMemcpyDeviceToHost, c->stream));
             J->coop_issued = true;
             J->cw_issued = cw_c;
             return;
@@ -1587,10 +1606,12 @@ void qrb_issue(BlockedQrcpJob<T> *J) {
 
 // to be called after the context's stream has been synchronised since qrb_issue(); true = factorization complete
 template <typename T>
+static bool qrb_finish_with(BlockedQrcpJob<T> *J, QrbState h, bool coop, bool optimistic);
+
+template <typename T>
 bool qrb_finish(BlockedQrcpJob<T> *J) {
     rc_context *c = J->c;
     QrbState h = *J->host_st;
-    const int64_t m = J->m, n = J->n, j0 = J->j0;
     bool coop = false;
     if (J->coop_issued) {
         if (h.pad0 == 1) {
@@ -1605,10 +1626,19 @@ bool qrb_finish(BlockedQrcpJob<T> *J) {
         }
         J->coop_issued = false;
     }
+    return qrb_finish_with(J, h, coop, false);
+}
+
+// the panel-end kernels for a panel whose state is h (read back by the host, or ASSUMED by the optimistic issue: cooperative
+// launch completed, all nbp steps made, some column is not a candidate; the norms flag is read on the device)
+template <typename T>
+static bool qrb_finish_with(BlockedQrcpJob<T> *J, QrbState h, bool coop, bool optimistic) {
+    rc_context *c = J->c;
+    const int64_t m = J->m, n = J->n, j0 = J->j0;
     const int kb = h.stopped ? h.kb : J->nbp;
     RC_REQUIRE(kb >= 1 && kb <= J->nbp, RC_PIVOTED_QR_ERROR, "geqp3_blocked: panel at %lld made %d steps", (long long)j0, kb);
     static const int check = env_int_b("RC_QRCP_CHECK", 0);
-    if (check) {
+    if (check && !optimistic) {
         ArenaMark mk(c);
         int *mark = c->alloc<int>((size_t)n + 4);
         fill_words(c, mark, ((size_t)n + 4) * sizeof(int), 0u);
@@ -1624,23 +1654,24 @@ bool qrb_finish(BlockedQrcpJob<T> *J) {
     }
     const int64_t rows = m - j0;
     const bool last = j0 + kb >= J->kmax;
+    const int *okp = optimistic ? J->opt_ok : nullptr;
     Mat<T> w = J->w;
     Mat<T> vpp = Mat<T>(J->vp.p, rows, kb, 1, J->vp.cs);
-    hipLaunchKernelGGL(k_qrb_build_vp<T>, dim3((unsigned)std::min<int64_t>(cdivb(rows, 256), 64), (unsigned)kb), dim3(256), 0, c->stream, w, (int)j0, J->st, vpp);
+    hipLaunchKernelGGL(k_qrb_build_vp<T>, dim3((unsigned)std::min<int64_t>(cdivb(rows, 256), 64), (unsigned)kb), dim3(256), 0, c->stream, w, (int)j0, J->st, vpp, okp);
     int ysplits = 1;
     if (h.have_noncand) {
         // Y = V^T A(j0:m, :) for every column: one read pass; used for the non-candidates only.  f32 with 16-byte aligned columns: the
         // streaming kernel k_qrb_vta (partial slabs, summed by k_qrb_finish); otherwise the MFMA GEMM
-        if (!qrb_vta_launch<T>(c, vpp, w.sub(j0, rows, 0, n), kb, J->Y, J->ldy, (int64_t)kNB * J->ldy, &ysplits)) {
+        if (!qrb_vta_launch<T>(c, vpp, w.sub(j0, rows, 0, n), kb, J->Y, J->ldy, (int64_t)kNB * J->ldy, &ysplits, okp)) {
             ysplits = 1;
             Mat<T> ym = rowmajor(J->Y, kb, n, J->ldy);
             gemm<T>(c, 1, vpp.t(), w.sub(j0, rows, 0, n), 0, ym);
         }
     }
-    if (coop) hipLaunchKernelGGL(k_qrb_build_t<T>, dim3(1), dim3(1024), 0, c->stream, J->coop.D, J->tau, (int)j0, kb, J->Tm);
+    if (coop) hipLaunchKernelGGL(k_qrb_build_t<T>, dim3(1), dim3(1024), 0, c->stream, J->coop.D, J->tau, (int)j0, kb, J->Tm, okp);
     else hipLaunchKernelGGL(k_qrb_scatter<T>, dim3((unsigned)cdivb(std::max(h.ncand, 1), 256)), dim3(256), 0, c->stream, w, (int)j0, kb, J->P, J->vn1);
     hipLaunchKernelGGL(k_qrb_finish<T>, dim3((unsigned)cdivb(n, 256)), dim3(256), 0, c->stream, w, (int)j0, kb, J->pos, J->is_cand, J->vn1, J->vn2, J->Fm, J->Y, J->ldy,
-                       J->Tm, vpp, J->flag, coop ? 1 : 0, ysplits, (int64_t)kNB * J->ldy);
+                       J->Tm, vpp, J->flag, coop ? 1 : 0, ysplits, (int64_t)kNB * J->ldy, okp);
     if (!last && rows - kb > 0) {
         // block update of everything below the panel, written as the transposed product so that the lanes of the
         // MFMA accumulator run along the column-major matrix' contiguous dimension:
@@ -1655,7 +1686,7 @@ bool qrb_finish(BlockedQrcpJob<T> *J) {
             static const int upd_wgs = env_int_b("RC_QRCP_UPDATE_WGS", 1024);  // every workgroup re-reads its rows of V: wide column strips amortise it
             const int cols_per_wg = (int)std::max<int64_t>(8, cdivb(n, std::max<int64_t>(1, upd_wgs / gx)));
             hipLaunchKernelGGL((k_qrb_block_update<T, RPT>), dim3(gx, (unsigned)cdivb(n, cols_per_wg)), dim3(256), 0, c->stream, w, (int)(j0 + kb), kb, (int)j0, vpp,
-                               kb, J->Fm, J->pos, J->is_cand, coop ? 1 : 0, cols_per_wg);
+                               kb, J->Fm, J->pos, J->is_cand, coop ? 1 : 0, cols_per_wg, okp);
         } else {
             Mat<T> ft = Mat<T>(J->Fm, n, kb, kNB, 1);
             gemm<T>(c, (T)-1, ft, vpp.sub(kb, rows - kb, 0, kb).t(), (T)1, w.sub(j0 + kb, rows - kb, 0, n).t());
@@ -1665,7 +1696,7 @@ bool qrb_finish(BlockedQrcpJob<T> *J) {
         // accuracy threshold together (vn1 / vn2 shrinks at the same rate everywhere), and recomputing them one flag at a
         // time would end a panel after every single step for hundreds of steps (which is what LAPACK's own ?geqp3 does there)
         hipLaunchKernelGGL(k_qrb_renorm<T>, dim3((unsigned)std::min<int64_t>(cdivb(n, 4), 4096)), dim3(256), 0, c->stream, w, (int)(j0 + kb), h.lsticc, J->pos, J->flag,
-                           J->vn1, J->vn2);
+                           J->vn1, J->vn2, optimistic ? J->st : (const QrbState *)nullptr, okp);
     }
     // a panel that the tau test ended early means the candidate set was too small for this spectrum
     if (J->keep_t) {   // keep the panel's T factor for the block form-Q
@@ -1678,6 +1709,81 @@ bool qrb_finish(BlockedQrcpJob<T> *J) {
     if (h.stop_tau && kb < J->nbp) J->cwant = std::min<int64_t>(n, kb < J->nbp / 2 ? J->cwant * 2 : J->cwant * 3 / 2);
     J->j0 += kb;
     return J->j0 >= J->kmax;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Optimistic issue.  The host reads a panel's state back only to learn what almost always holds for a truncated factorization
+// of a few panels (cfg5: two): the cooperative launch completed (pad0 == 1) and made all its steps.  Here ALL panels and their
+// panel ends are enqueued back to back on those assumptions, each panel's state is copied to its own pinned slot, and the host
+// checks the slots ONCE afterwards (qrb_verify_optimistic): one wait per factorization instead of one per panel, and in a batch
+// no wait at all until every matrix has been issued.  A failed check means the working matrix is garbage: the caller restores it
+// from its source and runs the per-panel path (qrb_issue / wait / qrb_finish), which handles every case.
+// Needs: cooperative panels for every panel of the job, no T factors kept (no Q wanted), no per-panel diagnostics.
+template <typename T>
+bool qrb_optimistic_possible(BlockedQrcpJob<T> *J) {
+    static const int on = env_int_b("RC_QRCP_OPTIMISTIC", 1), check = env_int_b("RC_QRCP_CHECK", 0), graph = env_int_b("RC_QRCP_GRAPH", 0);
+    if (!on || check || graph || !J->coop_ready || J->keep_t || J->j0 != 0) return false;
+    const int64_t panels = cdivb(J->kmax, kNB);
+    if (panels < 1 || panels > 16) return false;
+    // every panel must take the cooperative path: rows fit a wave's registers (qrb_issue's own test) at the panel's first row
+    const int64_t rows_first = J->m, rows_last = J->m - (panels - 1) * kNB;
+    return rows_first <= coop_rows_cap<T>() && rows_last >= 8;
+}
+
+// after a cooperative panel of the optimistic issue: did it complete and make the steps the host assumed?  (sticky: once cleared,
+// every kernel enqueued behind it on these assumptions returns at once, and the gates of the later panels do not open)
+__global__ void k_qrb_opt_check(const QrbState *st, int assumed_kb, int *ok) {
+    if (threadIdx.x == 0 && blockIdx.x == 0 && (st->pad0 != 1 || (st->stopped && st->kb != assumed_kb))) *ok = 0;
+}
+
+// slots of pinned state this context hands to optimistic jobs before somebody has to wait (rc_batch resets the cursor per call)
+template <typename T>
+bool qrb_issue_all_optimistic(BlockedQrcpJob<T> *J) {
+    rc_context *c = J->c;
+    const int panels = (int)cdivb(J->kmax, kNB);
+    const int cap = (int)(c->pinned_size / sizeof(QrbState));
+    if (c->pinned_cursor + panels > cap) return false;  // the caller waits, checks what is pending and resets the cursor
+    J->optimistic = true;
+    J->log_base = c->pinned_cursor;
+    J->log_n = 0;
+    c->pinned_cursor += panels;
+    fill_words(c, J->opt_ok, 2 * sizeof(int), 1u);
+    for (int p = 0; p < panels; ++p) {
+        qrb_issue(J);
+        if (!J->coop_issued) {  // (the device budget shrank: the step kernels were enqueued instead -- nothing behind them may run)
+            fill_words(c, J->opt_ok, 2 * sizeof(int), 0u);
+            J->opt_broken = true;
+            return true;
+        }
+        hipLaunchKernelGGL(k_qrb_opt_check, dim3(1), dim3(64), 0, c->stream, J->st, J->nbp, J->opt_ok);
+        J->coop_issued = false;
+        J->nbp_log.push_back(J->nbp);
+        QrbState h;
+        memset(&h, 0, sizeof(h));
+        h.pad0 = 1;
+        h.have_noncand = 1;
+        J->log_n = p + 1;
+        if (qrb_finish_with(J, h, true, true)) break;
+    }
+    return true;
+}
+
+// after the stream has been waited for: did every assumption hold?
+template <typename T>
+bool qrb_verify_optimistic(const QrbState *host_log, const std::vector<int> &nbp_log, bool broken) {
+    if (broken) return false;
+    for (size_t p = 0; p < nbp_log.size(); ++p) {
+        const QrbState &h = host_log[p];
+        if (h.pad0 != 1) return false;                       // the cooperative launch gave up (time-out, more candidates than waves)
+        if (h.stopped && h.kb != nbp_log[p]) return false;   // the panel ended early (tau test)
+    }
+    return true;
+}
+template <typename T>
+bool qrb_verify_optimistic(BlockedQrcpJob<T> *J) { return qrb_verify_optimistic<T>(J->host_st + J->log_base, J->nbp_log, J->opt_broken); }
+template <typename T>
+void qrb_optimistic_log(BlockedQrcpJob<T> *J, const QrbState **log, std::vector<int> *nbp_log, bool *broken) {
+    *log = J->host_st + J->log_base; *nbp_log = J->nbp_log; *broken = J->opt_broken;
 }
 
 // Q(:, 0:kq) = H_0 ... H_{k-1} [I ; 0] from the finished job, panel by panel from the last to the first:
@@ -1718,9 +1824,22 @@ void qrb_keep_t(BlockedQrcpJob<T> *J, bool keep) { J->keep_t = keep; }
 // w: m x n column-major working matrix (overwritten with the ?geqp3 output format: R on and above the
 // diagonal in position order, reflectors below, columns never moved); jpvt: n; tau: kmax
 template <typename T>
-void geqp3_blocked(rc_context *c, Mat<T> w, int64_t kmax, int64_t *jpvt, T *tau, Mat<T> q_out) {
+void geqp3_blocked(rc_context *c, Mat<T> w, int64_t kmax, int64_t *jpvt, T *tau, Mat<T> q_out, Mat<T> restore_from) {
     if (std::min(kmax, std::min(w.rows, w.cols)) <= 0) return;
     ProfScope ps(c, "op:geqp3_blocked %lldx%lld k=%lld", (long long)w.rows, (long long)w.cols, (long long)kmax);
+    if (restore_from.p && q_out.empty()) {
+        // all panels enqueued on the usual outcome, ONE wait, then the check (see qrb_issue_all_optimistic)
+        ArenaMark mark(c);
+        BlockedQrcpJob<T> *J = qrb_begin<T>(c, w, kmax, jpvt, tau);
+        struct Guard { BlockedQrcpJob<T> *j; ~Guard() { qrb_end(j); } } guard{J};
+        J->keep_t = false;
+        c->pinned_cursor = 0;
+        if (qrb_optimistic_possible(J) && qrb_issue_all_optimistic(J)) {
+            RC_HIP(hipStreamSynchronize(c->stream));
+            if (qrb_verify_optimistic(J)) return;
+            copy_mat(c, restore_from, w);  // an assumption failed: start over on a fresh copy, panel by panel
+        }
+    }
     ArenaMark mark(c);
     BlockedQrcpJob<T> *J = qrb_begin<T>(c, w, kmax, jpvt, tau);
     struct Guard { BlockedQrcpJob<T> *j; ~Guard() { qrb_end(j); } } guard{J};
@@ -1742,14 +1861,19 @@ extern "C" void rc_debug_qrc_timing(unsigned long long *out) { (void)hipMemcpyFr
     template bool qrb_finish<T>(BlockedQrcpJob<T> *);                                            \
     template void qrb_form_q<T>(BlockedQrcpJob<T> *, Mat<T>);                                    \
     template void qrb_end<T>(BlockedQrcpJob<T> *);                                               \
-    template void qrb_keep_t<T>(BlockedQrcpJob<T> *, bool);
+    template void qrb_keep_t<T>(BlockedQrcpJob<T> *, bool);                                      \
+    template bool qrb_optimistic_possible<T>(BlockedQrcpJob<T> *);                               \
+    template bool qrb_issue_all_optimistic<T>(BlockedQrcpJob<T> *);                              \
+    template bool qrb_verify_optimistic<T>(BlockedQrcpJob<T> *);                                 \
+    template bool qrb_verify_optimistic<T>(const QrbState *, const std::vector<int> &, bool);    \
+    template void qrb_optimistic_log<T>(BlockedQrcpJob<T> *, const QrbState **, std::vector<int> *, bool *);
 RC_INST_JOB(double)
 RC_INST_JOB(float)
 #undef RC_INST_JOB
 
 template bool geqp3_blocked_supported<double>(int64_t, int64_t, int64_t);
 template bool geqp3_blocked_supported<float>(int64_t, int64_t, int64_t);
-template void geqp3_blocked<double>(rc_context *, Mat<double>, int64_t, int64_t *, double *, Mat<double>);
-template void geqp3_blocked<float>(rc_context *, Mat<float>, int64_t, int64_t *, float *, Mat<float>);
+template void geqp3_blocked<double>(rc_context *, Mat<double>, int64_t, int64_t *, double *, Mat<double>, Mat<double>);
+template void geqp3_blocked<float>(rc_context *, Mat<float>, int64_t, int64_t *, float *, Mat<float>, Mat<float>);
 
 }  // namespace rc

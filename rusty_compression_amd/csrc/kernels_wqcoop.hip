@@ -70,12 +70,15 @@ __device__ inline unsigned ld_agent(const unsigned *p) { return __hip_atomic_loa
 // sync words: [0] finished-workgroup counter, [1] abort (1 = run time, 2 = gate)
 // The header slots are cleared on every launch (also on every replay of a captured graph): their
 // words carry the step number they belong to, and a stale word of an earlier launch must not pass.
-__global__ void k_coop_gate(unsigned *sem, unsigned need, unsigned budget, unsigned *sync, unsigned long long *hdr, int hdr_words) {
+// proceed (optional): a device word of the caller; 0 = do not even try (the optimistic issue of the blocked QRCP found one of its
+// assumptions broken: the cooperative kernel behind this gate then leaves through its "the gate gave up" exit, no budget is held)
+__global__ void k_coop_gate(unsigned *sem, unsigned need, unsigned budget, unsigned *sync, unsigned long long *hdr, int hdr_words, const int *proceed) {
     if (blockIdx.x != 0) return;
     for (int i = threadIdx.x; i < hdr_words; i += blockDim.x) __hip_atomic_store(hdr + i, 0ull, __ATOMIC_RELAXED, RC_AGENT);
     if (threadIdx.x != 0) return;
     st_agent(sync + 0, 0u);
     st_agent(sync + 2, 0u);  // (k_qrb_coop's commit counter)
+    if (proceed && *proceed == 0) { st_agent(sync + 1, 2u); return; }
     unsigned ab = 2u;
     for (int it = 0; it < kSpinLimit; ++it) {
         const unsigned old = __hip_atomic_fetch_add(sem, need, __ATOMIC_RELAXED, RC_AGENT);
@@ -583,11 +586,11 @@ unsigned coop_budget_units(int device) {
 
 // one-thread gate in front of a cooperative kernel: takes `need` units of the device-wide budget (released by the cooperative
 // kernel's last workgroup), clears the kernel's header words and its sync words
-void coop_gate_launch(rc_context *c, unsigned need, unsigned *sync, unsigned long long *hdr, int hdr_words) {
+void coop_gate_launch(rc_context *c, unsigned need, unsigned *sync, unsigned long long *hdr, int hdr_words, const int *proceed) {
     // (the caller checked need <= budget; the share of this process may have shrunk since -- another process arrived on the device --
     // in which case this launch still goes through once nothing else of this process holds units)
     const unsigned budget = std::max(coop_budget_units(c->device), need);
-    hipLaunchKernelGGL(k_coop_gate, dim3(1), dim3(256), 0, c->stream, coop_semaphore(c->device), need, budget, sync, hdr, hdr_words);
+    hipLaunchKernelGGL(k_coop_gate, dim3(1), dim3(256), 0, c->stream, coop_semaphore(c->device), need, budget, sync, hdr, hdr_words, proceed);
 }
 
 // One stage: NE 8-row blocks per column in registers (the live rows [row0, m) must fit: 8 NE >= m - row0), CPG columns per 8-lane group.

@@ -974,7 +974,7 @@ void column_id_rank(rc_context *c, Mat<T> a, int64_t k, Mat<T> cm, Mat<T> z, int
     if (!long_way && k < n && c->opt_blocked && !c->capturing && geqp3_blocked_supported<T>(m, n, k) &&
         !(c->opt_tsqr && tsqr_supported<T>(m, n)) && !(c->opt_wide_coop && wide_coop_supported<T>(m, n, c->device)) && !(c->opt_wide_lazy && wide_lazy_supported<T>(m, n))) {
         T *tau = c->alloc<T>((size_t)std::max<int64_t>(k, 1));
-        geqp3_blocked<T>(c, w, k, col_ind, tau, Mat<T>());
+        geqp3_blocked<T>(c, w, k, col_ind, tau, Mat<T>(), /*restore_from=*/a);
         column_id_from_qrcp(c, a, w, k, col_ind, cm, z);
         return;
     }

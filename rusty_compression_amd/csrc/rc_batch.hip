@@ -16,6 +16,7 @@
 // RCCL is opened at run time (dlopen) so that the library has no link-time dependency on it: hosts that never gather,
 // and the CPU-side symbol tests, do not need it.  Inside a PyTorch process the soname resolves to the copy torch loaded.
 #include "rc_common.hpp"
+#include <chrono>
 
 #include <dlfcn.h>
 #include <rccl/rccl.h>
@@ -166,12 +167,89 @@ void batch_column_id(rc_context *const *ctxs, int nctx, const rc_matrix *mats, i
         return false;
     };
     for (int l = 0; l < nctx; ++l) lanes[(size_t)l].c = ctxs[l];
+    // Optimistic schedule (default where it applies: blocked factorization on cooperative panels, no Q wanted): EVERY matrix is
+    // enqueued in full on its lane -- all panels on their usual outcome (qrb_issue_all_optimistic), then C, Z, ind -- with no host
+    // wait in between; one wait for all lanes at the end, then the per-panel states are checked and the (rare) matrices whose
+    // assumptions failed are redone through the per-panel pipeline below.  The lanes' chains then overlap on the GPU without the
+    // bubbles of a host round trip per panel (8 x 4096^2 f32, k = 64: 3.2 -> see DESIGN.md section 3).
+    std::vector<int> redo;
+    bool optimistic_done = false;
+    {
+        static const bool long_way = [] { const char *e = getenv("RC_COLUMN_ID_FORM_Q"); return e && atoi(e) != 0; }();
+        static const bool opt_on = [] { const char *e = getenv("RC_BATCH_OPTIMISTIC"); return !(e && atoi(e) == 0); }();
+        if (opt_on && !long_way && k < n && count > 0 && lanes[0].c->opt_blocked && geqp3_blocked_supported<T>(m, n, k)) {
+            struct Pending { int idx; const QrbState *log; std::vector<int> nbp; bool broken; };
+            std::vector<Pending> pending;
+            auto flush = [&] {
+                std::vector<rc_context *> all;
+                for (auto &ln : lanes) all.push_back(ln.c);
+                RC_REQUIRE(rc_synchronize_all(all.data(), (int32_t)all.size()) == RC_OK, RC_RUNTIME_ERROR, "batch_column_id: wait failed");
+                for (auto &pd : pending)
+                    if (!qrb_verify_optimistic<T>(pd.log, pd.nbp, pd.broken)) redo.push_back(pd.idx);
+                pending.clear();
+                for (auto &ln : lanes) ln.c->pinned_cursor = 0;
+            };
+            bool possible = true;
+            static const bool dbg = [] { const char *e = getenv("RC_BATCH_DEBUG"); return e && atoi(e) != 0; }();
+            const auto t_begin = std::chrono::steady_clock::now();
+            for (auto &ln : lanes) ln.c->pinned_cursor = 0;
+            for (int idx = 0; idx < count && possible; ++idx) {
+                Lane &ln = lanes[(size_t)(idx % nctx)];
+                DeviceGuardB dg(ln.c->device);
+                ln.idx = idx;
+                ln.c->reset_arena();
+                ln.w = tmp_cm<T>(ln.c, m, n);
+                ln.tau = ln.c->template alloc<T>((size_t)k);
+                ln.ind = ln.c->template alloc<int64_t>((size_t)n);
+                copy_mat(ln.c, from_c<T>(mats[idx]), ln.w);
+                ln.job = qrb_begin<T>(ln.c, ln.w, k, ln.ind, ln.tau);
+                qrb_keep_t(ln.job, false);
+                if (!qrb_optimistic_possible(ln.job)) {
+                    possible = false;
+                } else {
+                    if (!qrb_issue_all_optimistic(ln.job)) {  // no pinned slots left on this lane: wait, check, go on
+                        flush();
+                        RC_REQUIRE(qrb_issue_all_optimistic(ln.job), RC_RUNTIME_ERROR, "batch_column_id: no pinned state slots");
+                    }
+                    Pending pd;
+                    pd.idx = idx;
+                    qrb_optimistic_log(ln.job, &pd.log, &pd.nbp, &pd.broken);
+                    pending.push_back(std::move(pd));
+                    post(ln);
+                }
+                qrb_end(ln.job);
+                ln.job = nullptr;
+                ln.active = false;
+                if (!possible) {  // (first matrix only in practice: all matrices share one shape) -- everything through the pipeline below
+                    flush();
+                    redo.clear();
+                    for (int i2 = 0; i2 < count; ++i2) redo.push_back(i2);
+                }
+            }
+            const auto t_issued = std::chrono::steady_clock::now();
+            if (possible) flush();
+            if (dbg) {
+                const auto t_end = std::chrono::steady_clock::now();
+                fprintf(stderr, "rc_batch optimistic: %d matrices issued in %.3f ms, waited %.3f ms, %zu to redo\n", count,
+                        std::chrono::duration<double, std::milli>(t_issued - t_begin).count(), std::chrono::duration<double, std::milli>(t_end - t_issued).count(), redo.size());
+            }
+            optimistic_done = true;
+        }
+    }
+    // what is left to do through the per-panel schedules: everything, or the matrices the optimistic pass has to redo
+    std::vector<int> todo;
+    if (optimistic_done) todo = redo;
+    else for (int i2 = 0; i2 < count; ++i2) todo.push_back(i2);
+    const int count_all = count;
+    (void)count_all;
+    count = (int)todo.size();
+    auto mat_of = [&](int t) { return todo[(size_t)t]; };
     // RC_BATCH_LOCKSTEP=1: the round-1 schedule (all lanes issue, ONE wait for all, all lanes finish), kept for comparison.
     static const bool lockstep = [] { const char *e = getenv("RC_BATCH_LOCKSTEP"); return e && atoi(e) != 0; }();
     if (lockstep) {
         for (int base = 0; base < count; base += nctx) {
             int nact = 0;
-            for (int l = 0; l < nctx && base + l < count; ++l) nact += start(lanes[(size_t)l], base + l) ? 1 : 0;
+            for (int l = 0; l < nctx && base + l < count; ++l) nact += start(lanes[(size_t)l], mat_of(base + l)) ? 1 : 0;
             while (nact > 0) {
                 for_lanes([](Lane &ln) { return ln.active; }, [](Lane &ln) { qrb_issue(ln.job); });
                 // one wait for all lanes: an event on every stream first (see rc_synchronize_all)
@@ -216,7 +294,7 @@ void batch_column_id(rc_context *const *ctxs, int nctx, const rc_matrix *mats, i
                     if (ln.active) continue;
                     const int idx = next.fetch_add(1);
                     if (idx >= count) break;
-                    if (start(ln, idx)) {
+                    if (start(ln, mat_of(idx))) {
                         DeviceGuardB dg(ln.c->device);
                         qrb_issue(ln.job);
                         mark(ln);

@@ -114,6 +114,7 @@ struct rc_context {
     std::map<std::vector<uint64_t>, hipGraphExec_t> qrb_graphs;
     void *pinned = nullptr;             // small pinned host buffer for scalar read-backs
     size_t pinned_size = 0;
+    int pinned_cursor = 0;              // next free QrbState slot of `pinned` for optimistic blocked-QRCP jobs (kernels_qrblk.hip)
 
     // Tall-skinny factorizations: 1 = CholeskyQR2 fast path with certificate + Householder
     // fallback (default), 0 = always the Householder chain.  `health` is a device word the
@@ -223,7 +224,9 @@ template <typename T> void geqp3_inplace(rc_context *c, Mat<T> w, int64_t kmax, 
 // format as geqp3_inplace; reads one small struct back per panel (not capturable in a hipGraph)
 template <typename T> bool geqp3_blocked_supported(int64_t m, int64_t n, int64_t kmax);
 // q_out (m x kq column-major, may be empty): Q formed panel by panel with the T factors the panels built
-template <typename T> void geqp3_blocked(rc_context *c, Mat<T> w, int64_t kmax, int64_t *jpvt, T *tau, Mat<T> q_out);
+// restore_from (optional, only without q_out): the matrix w is a copy of -- enables the optimistic issue (all panels enqueued on the
+// usual outcome, one wait, a check; on a failed check w is restored from it and the per-panel path runs)
+template <typename T> void geqp3_blocked(rc_context *c, Mat<T> w, int64_t kmax, int64_t *jpvt, T *tau, Mat<T> q_out, Mat<T> restore_from = Mat<T>());
 // the same factorization as a resumable job (one host wait per panel): begin -> { issue, <stream synchronised>, finish } ... -> end
 template <typename T> struct BlockedQrcpJob;
 template <typename T> BlockedQrcpJob<T> *qrb_begin(rc_context *c, Mat<T> w, int64_t kmax, int64_t *jpvt, T *tau);
@@ -231,6 +234,12 @@ template <typename T> void qrb_issue(BlockedQrcpJob<T> *job);
 template <typename T> bool qrb_finish(BlockedQrcpJob<T> *job);
 template <typename T> void qrb_form_q(BlockedQrcpJob<T> *job, Mat<T> q);  // after completion
 template <typename T> void qrb_end(BlockedQrcpJob<T> *job);
+struct QrbState;
+template <typename T> bool qrb_optimistic_possible(BlockedQrcpJob<T> *job);
+template <typename T> bool qrb_issue_all_optimistic(BlockedQrcpJob<T> *job);   // false: no pinned slots left on the context (wait, check what is pending, reset c->pinned_cursor)
+template <typename T> bool qrb_verify_optimistic(BlockedQrcpJob<T> *job);
+template <typename T> bool qrb_verify_optimistic(const QrbState *host_log, const std::vector<int> &nbp_log, bool broken);
+template <typename T> void qrb_optimistic_log(BlockedQrcpJob<T> *job, const QrbState **log, std::vector<int> *nbp_log, bool *broken);
 template <typename T> void qrb_keep_t(BlockedQrcpJob<T> *job, bool keep);  // false: no Q will be formed, the panels' T factors need not be kept
 // short-wide matrices (m <= 256 << n): read-only "lazy" pivoted QR with the explicit m x m factor
 template <typename T> bool wide_lazy_supported(int64_t m, int64_t n);
@@ -243,7 +252,7 @@ void coop_prepare(int device);
 // device-wide budget of the cooperative kernels, in half compute units (kernels_wqcoop.hip)
 unsigned *coop_semaphore_of(int device);
 unsigned coop_budget_units(int device);
-void coop_gate_launch(rc_context *c, unsigned need, unsigned *sync, unsigned long long *hdr, int hdr_words);
+void coop_gate_launch(rc_context *c, unsigned need, unsigned *sync, unsigned long long *hdr, int hdr_words, const int *proceed = nullptr);
 // r(i, p) = (i <= p) ? w(i, jpvt[p]) : 0  for i < r.rows
 template <typename T> void extract_r(rc_context *c, Mat<T> w, const int64_t *jpvt, Mat<T> r);
 // qw (m x kq column-major) = H_0 ... H_{k-1} [I ; 0], reflector j stored in column jpvt[j] of w

@@ -1336,6 +1336,51 @@ def test_staged_wide_coop_qrcp_equals_the_single_launch_bit_for_bit():
     assert len(staged) == 12 and staged == single, [i for i, (x, y) in enumerate(zip(staged, single)) if x != y]
 
 
+_QRCP_OPTIMISTIC_SNIPPET = r"""
+import hashlib, os, sys
+import numpy as np, torch
+import rusty_compression_amd as rc
+from rusty_compression_amd import batch
+from oracle import ref_lapack as o
+out = []
+def dig(ts):
+    h = hashlib.sha256()
+    for t in ts:
+        h.update(t.contiguous().cpu().numpy().tobytes())
+    return h.hexdigest()
+# (a) Gaussian: every panel makes its 32 steps (the optimistic check holds); (b) decaying spectrum: panels end early on the tau test
+# (the check fails, the matrix is restored and redone panel by panel); (c) three panels, ragged shape, f64
+g = rc.random_gaussian((4096, 4096), rc.Rng(11), torch.float32)
+d = torch.from_numpy(o.random_approximate_low_rank_matrix((4096, 4096), 1.0, 1e-5, np.random.default_rng(5), np.float32)).cuda()
+r = rc.random_gaussian((1500, 2100), rc.Rng(12), torch.float64)
+for a, k in ((g, 64), (d, 64), (r, 80), (g, 40)):
+    out.append(dig(batch.column_id_rank(a, k)))
+mats = [rc.random_gaussian((2048, 2048), rc.Rng(20 + i), torch.float32) for i in range(5)] + [d[:2048, :2048].contiguous()]
+for res in batch.batch_column_id(mats, 48, lanes=4):
+    out.append(dig(res))
+print("DIGESTS " + " ".join(out))
+"""
+
+
+def test_optimistic_blocked_qrcp_equals_the_panel_by_panel_schedule_bit_for_bit():
+    """Round 3: the truncated blocked QRCP enqueues all its panels on their usual outcome and checks the panels' states once
+    (kernels_qrblk.hip, qrb_issue_all_optimistic); a failed check restores the working matrix and runs panel by panel.  Both outcomes
+    -- check holds (Gaussian), check fails (decaying spectrum: the tau test ends panels early) -- and the batch schedule built on it
+    must give the bits of the per-panel schedule (RC_QRCP_OPTIMISTIC=0, RC_BATCH_OPTIMISTIC=0)."""
+    import os
+    import subprocess
+    import sys
+
+    def digests(env):
+        res = subprocess.run([sys.executable, "-c", _QRCP_OPTIMISTIC_SNIPPET], env=dict(os.environ, **env), capture_output=True, text=True, timeout=600,
+                             cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+        assert res.returncode == 0, res.stdout[-1500:] + res.stderr[-1500:]
+        return [ln for ln in res.stdout.splitlines() if ln.startswith("DIGESTS ")][0].split()[1:]
+
+    opt, plain = digests({"RC_QRCP_OPTIMISTIC": "1", "RC_BATCH_OPTIMISTIC": "1"}), digests({"RC_QRCP_OPTIMISTIC": "0", "RC_BATCH_OPTIMISTIC": "0"})
+    assert len(opt) == 10 and opt == plain, [i for i, (x, y) in enumerate(zip(opt, plain)) if x != y]
+
+
 def test_wide_coop_qrcp_ties_take_the_first_position():
     """Equal column norms everywhere: idamax semantics = lowest position first, across workgroup boundaries."""
     m, n = 16, 1024
