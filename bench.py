@@ -102,7 +102,7 @@ def parse_args(argv=None):
     ap.add_argument("--config", choices=("cfg3", "cfg5"), default="cfg3",
                     help="cfg3 (default, the headline): 8192^2 f64 rank-128 rSVD+ID, independent matrices per GPU.  cfg5: BASELINE.json configs[4], "
                          "4096^2 f32 rank-64 column ID, --matrices-per-gpu (8) per rank through rc_batch_column_id_f32 + the factor gather to rank 0")
-    ap.add_argument("--streams", type=int, default=40, help="independent compressions in flight per GPU")
+    ap.add_argument("--streams", type=int, default=44, help="independent compressions in flight per GPU")
     ap.add_argument("--size", type=int, default=None, help="matrix size (cfg3: 8192, cfg5: 4096)")
     ap.add_argument("--rank", type=int, default=None, help="target rank (cfg3: 128, cfg5: 64)")
     ap.add_argument("--oversample", type=int, default=5)
