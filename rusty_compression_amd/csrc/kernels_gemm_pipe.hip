@@ -922,6 +922,16 @@ bool gemm_f64p_launch(rc_context *c, const GemmArgs<double> &g, int alay, int bl
         if (blay == 1 && bm == 136 && bn == 256 && wm == 2 && wn == 4 && orient == 0 && launch_d<1, 136, 256, 16, 2, 4, 0>(c, g)) return true;
         if (direct >= 2 && blay == 0 && bm == 128 && bn == 256 && wm == 1 && wn == 8 && orient == 1 && launch_d<0, 128, 256, 16, 1, 8, 1>(c, g)) return true;
     }
+    // the Gram products of the CholeskyQR passes (Y^T Y: K-contiguous both; Q1^T Q1 on the row-major Q1: M- / N-contiguous): one
+    // 144 x 144 tile on 3 x 3 waves, K split over the workgroups -- the compiler-scheduled loop of kernels_gemm.hip spends ~5 us per
+    // K tile on them (load -> LDS -> MFMA in sequence), this one keeps the next tile's loads in flight (RC_GEMM_PIPE_GRAM=0: off)
+    static const int gram = [] { const char *e = getenv("RC_GEMM_PIPE_GRAM"); return e ? atoi(e) : 1; }();
+    if (gram) {
+        RC_PIPE_CASE(0, 1, 144, 144, 3, 3, 0)
+        RC_PIPE_CASE(1, 0, 144, 144, 3, 3, 0)
+    }
+    // (the K = 128 shallow products -- Q = range Q_b, C = Q R11, U = range U_b -- through this loop on 128 x 128 tiles measured
+    // neutral to slightly slower in the headline, 1072 / 1083 against 1084 / 1084: eight K tiles do not amortise the prologue)
     RC_PIPE_CASE(1, 1, 136, 256, 2, 4, 0)  // the sketch (transposed problem): 68 x 64 wave tiles
     RC_PIPE_CASE(1, 0, 128, 256, 1, 8, 1)  // the projection: 128 x 32 wave tiles
 #undef RC_PIPE_CASE
