@@ -130,7 +130,13 @@ rc_status rc_graph_destroy(rc_context *ctx, void *graph_exec);
  * split K (a lone launch) or not (many compressions in flight): results differ by summation order; (ii) a call recorded into a
  * hipGraph cannot read scalars back, so general-shape pivoted QRs run the per-step chain there and the blocked panels eagerly:
  * same pivots on the data-determined prefix, factors equal to rounding (tests: test_captured_pivoted_qr_of_a_blocked_eligible_shape…).
- * The cfg3 pipeline (rc_rsvd_id_*) takes the same path eagerly and captured: its replays equal the eager result bit for bit. */
+ * The cfg3 pipeline (rc_rsvd_id_*) takes the same path eagerly and captured: its replays equal the eager result bit for bit.
+ * Environment switches that select between implementations (measurement aids, read once per process) change rounding the same
+ * way and are NOT part of the promise: RC_TSQR_FOLD (order of the small factors of the tall-skinny QR), RC_QRCP_CAND_MB (which
+ * columns of a blocked panel are updated reflector by reflector and which through the block update: last bits of R12 / Z),
+ * RC_GEMM_LANES_TARGET, RC_GEMM_SMALL_TARGET (split-K counts), RC_GEMM_PIPE_* / RC_GEMM_RING (which loop runs a product).
+ * Schedules that only change WHEN or WHERE the same arithmetic is issued -- RC_WQ_STAGES, RC_QRCP_OPTIMISTIC, RC_BATCH_OPTIMISTIC,
+ * RC_QRCP_KEEP_DIRECT, RC_ID_FUSED -- give identical bits (tested for the staged k_wq_coop and the optimistic blocked QRCP). */
 /* RC_OPT_POWER_ITERATION_FIXED (default 0): rc_sample_range_power_iteration_* performs it_count power steps
  * (Y <- A orth(A^H orth(Y))) as the reference documents; 0 reproduces the reference's behaviour, where a shadowed
  * loop variable leaves exactly one step (src/random_sampling.rs:145-153). */
