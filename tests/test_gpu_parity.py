@@ -1381,6 +1381,57 @@ def test_optimistic_blocked_qrcp_equals_the_panel_by_panel_schedule_bit_for_bit(
     assert len(opt) == 10 and opt == plain, [i for i, (x, y) in enumerate(zip(opt, plain)) if x != y]
 
 
+_SCHEDULING_SNIPPET = r"""
+import ctypes, hashlib
+import torch
+import rusty_compression_amd as rc
+from rusty_compression_amd import _lib
+CT = rc.CompressionType
+out = []
+def dig(ts):
+    h = hashlib.sha256()
+    for t in ts:
+        h.update(t.contiguous().cpu().numpy().tobytes())
+    return h.hexdigest()
+# QRTraits::column_id / LQTraits::row_id through the Z kernel (rank-deficient branch), tall, wide and square inputs, f64 and f32
+for dt, shape, k, seed in ((torch.float64, (300, 200), 50, 1), (torch.float64, (64, 2048), 40, 2), (torch.float32, (500, 700), 96, 3)):
+    a = rc.random_gaussian(shape, rc.Rng(seed), dt)
+    cid = rc.QR.compute_from(a).compress(CT.RANK(k)).column_id()
+    rid = rc.LQ.compute_from(a).compress(CT.RANK(k)).row_id()
+    out.append(dig((cid.c, cid.z, cid.col_ind, rid.x, rid.r, rid.row_ind)))
+# the fused cfg3 call at a reduced size: B = Q^H A read in place by the cooperative QRCP, then overwritten by the SVD consumer
+m = n = 2048; k, p = 64, 5
+a = rc.random_gaussian((m, n), rc.Rng(9), torch.float64)
+mk = lambda r, c: torch.empty((r, c), dtype=torch.float64, device="cuda")
+b = dict(range_q=mk(m, k), u=mk(m, k), s=torch.empty(k, dtype=torch.float64, device="cuda"), vt=mk(k, n), qr_q=mk(m, k), qr_r=mk(k, n),
+         qr_ind=torch.empty(n, dtype=torch.int64, device="cuda"), id_c=mk(m, k), id_z=mk(k, n))
+o_ = _lib.rc_rsvd_id_out(_lib.mat(b["range_q"]), _lib.mat(b["u"]), ctypes.c_void_p(b["s"].data_ptr()), _lib.mat(b["vt"]), _lib.mat(b["qr_q"]), _lib.mat(b["qr_r"]),
+                         ctypes.c_void_p(b["qr_ind"].data_ptr()), _lib.mat(b["id_c"]), _lib.mat(b["id_z"]))
+_lib.default_context().call("rc_rsvd_id_f64", _lib.mat(a), ctypes.c_int64(k), ctypes.c_int64(p), _lib.mat(None), ctypes.c_uint64(3), ctypes.byref(o_))
+torch.cuda.synchronize()
+out.append(dig(b.values()))
+print("DIGESTS " + " ".join(out))
+"""
+
+
+def test_scheduling_switches_give_identical_bits():
+    """include/rusty_compression_amd.h, "Reproducibility": RC_ID_FUSED (Z of the ID in one launch instead of identity + copy + triangular
+    solve + inverse permutation + gather) and RC_QRCP_KEEP_DIRECT (the cooperative QRCP reads B = Q^H A where it lies instead of a
+    working copy) only change how the same arithmetic is issued: every output bit for bit."""
+    import os
+    import subprocess
+    import sys
+
+    def digests(env):
+        res = subprocess.run([sys.executable, "-c", _SCHEDULING_SNIPPET], env=dict(os.environ, **env), capture_output=True, text=True, timeout=600,
+                             cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+        assert res.returncode == 0, res.stdout[-1500:] + res.stderr[-1500:]
+        return [ln for ln in res.stdout.splitlines() if ln.startswith("DIGESTS ")][0].split()[1:]
+
+    new, old = digests({"RC_ID_FUSED": "1", "RC_QRCP_KEEP_DIRECT": "1"}), digests({"RC_ID_FUSED": "0", "RC_QRCP_KEEP_DIRECT": "0"})
+    assert len(new) == 4 and new == old, [i for i, (x, y) in enumerate(zip(new, old)) if x != y]
+
+
 def test_wide_coop_qrcp_ties_take_the_first_position():
     """Equal column norms everywhere: idamax semantics = lowest position first, across workgroup boundaries."""
     m, n = 16, 1024
