@@ -1341,7 +1341,6 @@ import hashlib, os, sys
 import numpy as np, torch
 import rusty_compression_amd as rc
 from rusty_compression_amd import batch
-from oracle import ref_lapack as o
 out = []
 def dig(ts):
     h = hashlib.sha256()
@@ -1351,7 +1350,12 @@ def dig(ts):
 # (a) Gaussian: every panel makes its 32 steps (the optimistic check holds); (b) decaying spectrum: panels end early on the tau test
 # (the check fails, the matrix is restored and redone panel by panel); (c) three panels, ragged shape, f64
 g = rc.random_gaussian((4096, 4096), rc.Rng(11), torch.float32)
-d = torch.from_numpy(o.random_approximate_low_rank_matrix((4096, 4096), 1.0, 1e-5, np.random.default_rng(5), np.float32)).cuda()
+def decaying(n, smin, seed):   # the reference's recipe (src/random_matrix.rs:70-93) with torch's QR on the device: input generation only
+    gen = torch.Generator(device="cuda").manual_seed(seed)
+    u = torch.linalg.qr(torch.randn(n, n, dtype=torch.float64, device="cuda", generator=gen)).Q
+    v = torch.linalg.qr(torch.randn(n, n, dtype=torch.float64, device="cuda", generator=gen)).Q
+    return ((u * torch.logspace(0, float(np.log10(smin)), n, dtype=torch.float64, device="cuda")) @ v.T).to(torch.float32).contiguous()
+d = decaying(4096, 1e-5, 5)
 r = rc.random_gaussian((1500, 2100), rc.Rng(12), torch.float64)
 for a, k in ((g, 64), (d, 64), (r, 80), (g, 40)):
     out.append(dig(batch.column_id_rank(a, k)))
