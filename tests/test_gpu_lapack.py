@@ -61,6 +61,25 @@ def test_geqp3_and_orgqr_match_lapack_output_format(dtype, shape):
     assert rel(npy(rc.orgqr(fo, tauo[:kk])), o.orgqr_raw(fo, tauo[:kk])) <= tol
 
 
+@pytest.mark.parametrize("shape", [(8192, 133), (128, 8192)])
+def test_geqp3_at_the_headline_shapes_of_cfg3(shape):
+    """The two pivoted QRs of a cfg3 compression at their full sizes (the sketch Y: 8192 x 133, the projection B: 128 x 8192; f64)
+    through the LAPACK seam: pivots on the determined prefix, R and tau against dgeqp3, Q against dorgqr."""
+    dt = np.dtype(np.float64)
+    a = _mat(np.float64, shape, 77)
+    m, n = shape
+    k = min(m, n)
+    f, jp, tau = (npy(t) for t in rc.geqp3(a))
+    fo, jpo, tauo = o.geqp3_raw(a)
+    r, ro = np.triu(f[:k]), np.triu(fo[:k])
+    ns = agreed_pivot_prefix(jp, r, jpo, ro, np.float64)
+    assert is_permutation(jp, n) and ns >= k // 2, f"only {ns} of {k} pivots agree"
+    assert rel(r[:ns, :ns], ro[:ns, :ns]) <= FACTOR[dt] and rel(tau[:ns], tauo[:ns]) <= 50 * FACTOR[dt]
+    q = npy(rc.orgqr(f, tau))
+    assert rel(q @ r, a[:, jp]) <= RECON[dt] and rel(q.T @ q, np.eye(k)) <= RECON[dt]
+    assert rel(npy(rc.orgqr(fo, tauo)), o.orgqr_raw(fo, tauo)) <= FACTOR[dt]
+
+
 @pytest.mark.parametrize("dtype", DTYPES)
 def test_geqp3_truncated_and_strided_views(dtype):
     dt = np.dtype(dtype)
